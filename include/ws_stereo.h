@@ -1,0 +1,172 @@
+/*
+ * ws_stereo.h -- C-ABI of the MI355X-native WindowSearch (dense block matching).
+ *
+ * This is the drop-in boundary for the reference's src/WindowSearch stage: plain
+ * pointers and sizes, no OpenCV / torch / C++ types.  Every entry point names
+ * the reference interface it replaces (paths relative to the reference root).
+ * The C++ facade with the reference's class names lives in
+ * stereo_reconstruction_amd/host/window_search.hpp; the binding a maintainer of
+ * the reference would add is shown in INTEGRATION.md.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is no CPU
+ * fallback: without a usable HIP device ws_create() fails with WS_ERR_HIP.
+ *
+ * Images: 8-bit, 3 channels interleaved in cv::imread order (BGR), row-major,
+ * `stride` bytes per row (CV_8UC3, BlockSearch.cpp:41, :105).  Left and right
+ * may differ in size (BlockSearch.cpp:25-30).  Disparity maps: row-major,
+ * integer-valued unless sub-pixel refinement is on.
+ */
+#ifndef WS_STEREO_H
+#define WS_STEREO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_VERSION 100 /* 0.1.0 */
+
+/* status codes (the reference has none: it throws cv::Exception / loops forever) */
+enum {
+    WS_OK = 0,
+    WS_ERR_ARG = -1,         /* null pointer, bad size / stride / enum */
+    WS_ERR_GEOMETRY = -2,    /* the reference would throw cv::Exception: even blockSize in the
+                                left view (BlockSearch.cpp:46-49), left ROI outside the image in
+                                the right view (BlockSearch.cpp:151-154) */
+    WS_ERR_UNSUPPORTED = -3, /* legal for the reference, not implemented on the device yet */
+    WS_ERR_HIP = -4,         /* HIP runtime error (see ws_last_error) */
+    WS_ERR_IO = -5,          /* file could not be read / written / parsed */
+    WS_ERR_NOMEM = -6
+};
+
+/* which reference method the call stands for */
+enum {
+    WS_VIEW_LEFT = 0,   /* BlockSearch::computeDisparityMapLeft   (BlockSearch.cpp:24-86)  */
+    WS_VIEW_RIGHT = 1,  /* BlockSearch::computeDisparityMapRight  (BlockSearch.cpp:88-179) */
+    WS_VIEW_LINEAR = 2  /* LinearSearch::computeDisparityMap      (LinearSearch.cpp:10-59) */
+};
+
+enum {
+    WS_COST_SSD = 0, /* the reference's cost: cv::norm(absdiff, NORM_L2) (BlockSearch.cpp:64-66) */
+    WS_COST_SAD = 1  /* extension: NORM_L1 in the same loops (BASELINE.json configs 1 and 3) */
+};
+
+enum { WS_OUT_F32 = 0, WS_OUT_F64 = 1 }; /* F64 = the reference's CV_64F maps (BlockSearch.cpp:33) */
+
+typedef struct {
+    const uint8_t *data; /* host pointer for *_host calls, device pointer for *_device calls */
+    int width;
+    int height;
+    int stride;          /* bytes per row, >= 3 * width */
+} ws_image;
+
+/*
+ * The constructor + call arguments of the reference, in one struct.
+ *   BlockSearch(L, R, blockSize, minDisparity, maxDisparity)        BlockSearch.h:11-15
+ *   computeDisparityMapLeft(smoothFactor)                            BlockSearch.h:28
+ *   computeDisparityMapRight(smoothFactor, varBlock, thres)          BlockSearch.h:37
+ *   LinearSearch(L, R).computeDisparityMap(smoothFactor)             LinearSearch.h:13-19
+ * Use ws_params_default() and then set what differs.
+ */
+typedef struct {
+    int view;             /* WS_VIEW_* */
+    int cost;             /* WS_COST_* (LINEAR ignores it: always the Euclidean pixel distance) */
+    int block_size;       /* blockSize (LINEAR ignores it) */
+    int min_disparity;    /* minDisparity: read by the right view only (BlockSearch.cpp:147) */
+    int max_disparity;    /* maxDisparity: left tries d = maxD..1, right d = minD..maxD-1 */
+    double smooth_factor; /* smoothFactor; only 1.0 runs on the device so far */
+    int var_block;        /* varBlock (right view); not on the device yet */
+    double thres;         /* thres for varBlock, default 19.0 (BlockSearch.h:37) */
+    int subpixel;         /* extension: parabolic refinement on the aggregated integer cost */
+    int linear_range;     /* LinearSearch's hard-coded 200 candidates (LinearSearch.cpp:32) */
+} ws_params;
+
+typedef struct ws_context ws_context; /* one per device; not to be shared between threads */
+
+/* ---- life cycle ------------------------------------------------------------------- */
+int ws_version(void);
+void ws_params_default(ws_params *p);
+/* Open HIP device `device`.  Owns a stream, scratch planes and staging buffers. */
+int ws_create(int device, ws_context **out);
+void ws_destroy(ws_context *ctx);
+/* Text of the last error on this context (or of the last failed ws_create if ctx == NULL). */
+const char *ws_last_error(const ws_context *ctx);
+int ws_device_count(void);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+/*
+ * Synchronous call on host buffers; replaces
+ *   BlockSearch(L,R,bs,minD,maxD).computeDisparityMapLeft/Right(...)   BlockSearch.cpp:24-179
+ *   LinearSearch(L,R).computeDisparityMap(s)                           LinearSearch.cpp:10-59
+ * as called from ImageRectifier::computeDisparityMapLeft/Right (rectification.cpp:66-88)
+ * and rectification_main.cpp:194-195.
+ * out: h1 x w1 (LEFT) or h2 x w2 (RIGHT, LINEAR) elements of out_dtype, out_stride in
+ * elements.  Copies in, runs, copies out, returns when the map is complete.
+ */
+int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left,
+                   const ws_image *right, void *out, int out_stride, int out_dtype);
+
+/*
+ * The same on device-resident buffers (images already in HBM, float32 map written to HBM),
+ * enqueued on `stream` (a hipStream_t; NULL = the context's own stream).  Returns after
+ * enqueueing; order / wait on the stream as usual.  This is what bench.py times.
+ */
+int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_dev,
+                     const ws_image *right_dev, float *out_dev, int out_stride, void *stream);
+
+/*
+ * Batched host form for many independent pairs (BASELINE.json config 4): enqueue copies +
+ * kernels for one pair on the context's stream with pinned staging, return at once;
+ * ws_wait() blocks until every enqueued pair's map has landed in its `out`.
+ */
+int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left,
+                    const ws_image *right, void *out, int out_stride, int out_dtype);
+int ws_wait(ws_context *ctx);
+
+/* ---- measurement ------------------------------------------------------------------ */
+/* hipEvent pair on `stream` (NULL = context stream): begin, enqueue work, end -> elapsed ms. */
+int ws_timer_begin(ws_context *ctx, void *stream);
+int ws_timer_end(ws_context *ctx, void *stream, float *elapsed_ms);
+/*
+ * After a ws_search_* call: the kernel that dominates it and how the path was tiled
+ * (name as it appears in a rocprofv3 kernel trace, threads per workgroup, workgroups,
+ * dynamic LDS bytes).  For reports; not part of the reference's surface.
+ */
+int ws_last_launch_info(const ws_context *ctx, char *kernel_name, int name_cap,
+                        int *threads, int *workgroups, int *lds_bytes);
+/* Tuning knob for the LDS tile sweep of BASELINE.json config 3: 0 = automatic. */
+int ws_set_tuning(ws_context *ctx, int x_runs_per_tile, int strip_rows, int threads);
+
+/* ---- Middlebury plumbing around the path ------------------------------------------ */
+/*
+ * PFM ("Pf", one channel): replaces the Middlebury SDK ReadImageVerb the reference uses for
+ * disp0GT.pfm (data_loader.cpp:110-125).  Rows are returned top-to-bottom; unknown = +inf.
+ * ws_pfm_read allocates *data with malloc (release with ws_free).
+ */
+int ws_pfm_read(const char *path, float **data, int *width, int *height);
+int ws_pfm_write(const char *path, const float *data, int width, int height, int stride);
+void ws_free(void *p);
+/*
+ * calib.txt: cam0 / cam1 as the reference parses them (data_loader.cpp:141-164), row-major
+ * 3x3 each, plus the keys it leaves unread (ndisp, doffs, baseline, width, height; -1 if absent).
+ */
+typedef struct {
+    float cam0[9];
+    float cam1[9];
+    float doffs, baseline;
+    int width, height, ndisp;
+} ws_calib;
+int ws_calib_read(const char *path, ws_calib *out);
+/*
+ * evaldisp (utils.cpp:123-168): the bad-pixel metric ("bad-2.0" = badthresh 2.0).
+ * res[0]=n, res[1]=bad %, res[2]=invalid %, res[3]=total bad %, res[4]=avgErr, res[5]=valid %.
+ */
+int ws_evaldisp(const float *disp, const float *gt, const uint8_t *mask, int width,
+                int height, float badthresh, float maxdisp, int rounddisp, double res[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WS_STEREO_H */

@@ -1,0 +1,589 @@
+// ws_capi.cpp -- the C-ABI of include/ws_stereo.h: argument checks that stand in for the
+// reference's cv::Exception paths, reduction of the three reference methods to the canonical
+// search (ws_kernels.h), scratch / staging memory owned by the context, and the Middlebury
+// plumbing (PFM, calib.txt, evaldisp).  Compiled with hipcc; no compute happens on the host.
+#include "../../include/ws_stereo.h"
+#include "ws_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace wsamd;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Job { // one pair in flight on the batched host path
+    void *pin_in = nullptr, *pin_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    void *user_out = nullptr;
+    int w = 0, h = 0, out_stride = 0, dtype = 0;
+    uint8_t *d_left = nullptr, *d_right = nullptr;
+    float *d_out = nullptr;
+    double *d_out64 = nullptr;
+    bool busy = false;
+};
+
+std::string g_create_error;
+
+} // namespace
+
+struct ws_context {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf plane_a, plane_b, bias, d_left, d_right, d_out, d_out64;
+    std::vector<Job> jobs;
+    std::string err;
+    std::string last_kernel;
+    int last_threads = 0, last_wgs = 0, last_lds = 0;
+    int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
+};
+
+namespace {
+
+int fail(ws_context *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define WS_HIP(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, WS_ERR_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),        \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+int ensure(ws_context *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return WS_OK;
+    if (b.p) WS_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    WS_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return WS_OK;
+}
+
+bool image_ok(const ws_image *im)
+{
+    return im && im->data && im->width > 0 && im->height > 0 && im->stride >= 3 * im->width;
+}
+
+int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (!p || !image_ok(L) || !image_ok(R)) return fail(ctx, WS_ERR_ARG, "null or malformed image / params");
+    if (p->view != WS_VIEW_LEFT && p->view != WS_VIEW_RIGHT && p->view != WS_VIEW_LINEAR)
+        return fail(ctx, WS_ERR_ARG, "unknown view %d", p->view);
+    if (p->cost != WS_COST_SSD && p->cost != WS_COST_SAD) return fail(ctx, WS_ERR_ARG, "unknown cost %d", p->cost);
+    if (p->view != WS_VIEW_LINEAR && (p->block_size < 1 || p->block_size > 63))
+        return fail(ctx, WS_ERR_ARG, "blockSize %d outside [1,63]", p->block_size);
+    if (p->view == WS_VIEW_LINEAR && p->linear_range < 1) return fail(ctx, WS_ERR_ARG, "linear_range < 1");
+    if (p->smooth_factor != 1.0)
+        return fail(ctx, WS_ERR_UNSUPPORTED,
+                    "smoothFactor %.3f: only 1.0 runs on the device (raster-order dependency, BlockSearch.cpp:68-73)",
+                    p->smooth_factor);
+    if (p->var_block && p->view == WS_VIEW_RIGHT)
+        return fail(ctx, WS_ERR_UNSUPPORTED, "varBlock is not implemented on the device (BlockSearch.cpp:129-142)");
+    if (p->subpixel && p->view == WS_VIEW_LINEAR) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel on LinearSearch");
+    const int h1 = L->height, w1 = L->width, h2 = R->height, w2 = R->width;
+    const int height = std::min(h1, h2);
+    const int half = (p->block_size - 1) / 2;
+    if (p->view == WS_VIEW_LEFT) {
+        // Rect(x-half, y-half, bs, bs) leaves the image for even bs (BlockSearch.cpp:46-49)
+        if ((p->block_size & 1) == 0 && height - 2 * half > 0 && w1 - 2 * half > 0)
+            return fail(ctx, WS_ERR_GEOMETRY, "even blockSize %d: the reference throws cv::Exception", p->block_size);
+    } else if (p->view == WS_VIEW_RIGHT && p->max_disparity > p->min_disparity) {
+        if (p->min_disparity < 0)
+            return fail(ctx, WS_ERR_GEOMETRY, "minDisparity < 0: left ROI starts before column 0 (BlockSearch.cpp:151)");
+        // leftImage_(Rect(.., y-up, .., up+down)) needs y + down <= h1 (BlockSearch.cpp:151-154)
+        for (int y = 0; y < height; ++y) {
+            const int down = std::min(h2 - y - 1, half);
+            if (y + down > h1)
+                return fail(ctx, WS_ERR_GEOMETRY, "left image too short for the right view window at row %d", y);
+        }
+    }
+    (void)w2;
+    return WS_OK;
+}
+
+// Reduce LEFT / RIGHT to the canonical search.  Returns false when no marching region exists.
+bool make_canon(const ws_params *p, const ws_image *L, const ws_image *R, Canon *c)
+{
+    const int h1 = L->height, w1 = L->width, h2 = R->height, w2 = R->width;
+    const int height = std::min(h1, h2);
+    const int half = (p->block_size - 1) / 2;
+    Canon k{};
+    k.ssd = p->cost == WS_COST_SSD;
+    if (p->view == WS_VIEW_LEFT) {
+        k.wa = w1; k.ha = h1; k.wb = w2; k.hb = h2;
+        k.ww = k.wh = p->block_size;
+        k.wx0 = k.wy0 = -half;
+        k.boff = 0;
+        k.d_lo = 1; k.d_hi = p->max_disparity;
+        k.b_lo = half; k.b_hi = w2 - half - 1;
+        k.ox0 = half; k.ox1 = w1 - half;
+        k.oy0 = half; k.oy1 = height - half;
+        k.prefer_large = 1; k.mirror = 0; k.fallback_neg = 0;
+    } else if (p->view == WS_VIEW_RIGHT) {
+        if (half < 1) return false;
+        k.wa = w2; k.ha = h2; k.wb = w1; k.hb = h1;
+        k.ww = k.wh = 2 * half;
+        k.wx0 = 1 - half; k.wy0 = -half;
+        k.boff = w1 - w2;
+        k.d_lo = p->min_disparity; k.d_hi = p->max_disparity - 1;
+        k.b_lo = half; k.b_hi = w1 - 1 - half;
+        k.ox0 = half; k.ox1 = w2 - half;
+        k.oy0 = half; k.oy1 = std::min(h2 - half, height);
+        k.prefer_large = 0; k.mirror = 1; k.fallback_neg = 1;
+    } else {
+        return false;
+    }
+    *c = k;
+    return k.ox1 > k.ox0 && k.oy1 > k.oy0 && k.d_hi >= k.d_lo;
+}
+
+int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
+               float *out, int out_stride, hipStream_t s)
+{
+    const int ow = p->view == WS_VIEW_LEFT ? L->width : R->width;
+    if (out_stride < ow) return fail(ctx, WS_ERR_ARG, "out_stride %d < width %d", out_stride, ow);
+
+    GenericArgs ga{};
+    ga.L = L->data; ga.R = R->data;
+    ga.w1 = L->width; ga.h1 = L->height; ga.s1 = L->stride;
+    ga.w2 = R->width; ga.h2 = R->height; ga.s2 = R->stride;
+    ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
+    ga.block_size = p->block_size; ga.min_d = p->min_disparity; ga.max_d = p->max_disparity;
+    ga.linear_range = p->linear_range;
+    ga.out = out; ga.out_pitch = out_stride;
+
+    Canon c{};
+    MarchLaunch m{};
+    bool march = make_canon(p, L, R, &c) &&
+                 march_plan(c, ctx->num_cus, ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads, &m);
+    if (march) {
+        Plane pa{}, pb{};
+        march_plane_geometry(c, m, &pa.pad, &pa.pitch, &pb.pad, &pb.pitch);
+        int rc;
+        if ((rc = ensure(ctx, ctx->plane_a, (size_t)pa.pitch * c.ha * 4)) != WS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->plane_b, (size_t)pb.pitch * c.hb * 4)) != WS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->bias, (size_t)pb.pitch * c.ha * 4)) != WS_OK) return rc;
+        pa.data = static_cast<uint32_t *>(ctx->plane_a.p);
+        pb.data = static_cast<uint32_t *>(ctx->plane_b.p);
+        const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
+        const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
+        WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, c.mirror, pa, s));
+        WS_HIP(ctx, launch_pack(ib->data, ib->width, ib->height, ib->stride, c.mirror, pb, s));
+        WS_HIP(ctx, launch_bias(c, m, pb, static_cast<int32_t *>(ctx->bias.p), s));
+        WS_HIP(ctx, launch_march(c, m, pa, pb, static_cast<int32_t *>(ctx->bias.p), out, out_stride, s));
+        if (c.mirror) {
+            ga.skip_x0 = c.wa - c.ox1; ga.skip_x1 = c.wa - c.ox0;
+        } else {
+            ga.skip_x0 = c.ox0; ga.skip_x1 = c.ox1;
+        }
+        ga.skip_y0 = c.oy0; ga.skip_y1 = c.oy1;
+        ctx->last_kernel = march_kernel_name(c, m);
+        ctx->last_threads = m.threads;
+        ctx->last_wgs = m.tiles * m.strips;
+        ctx->last_lds = (int)m.lds_bytes;
+    } else {
+        ctx->last_kernel = "ws_generic_kernel";
+        ctx->last_threads = 256;
+        ctx->last_wgs = ((ow + 255) / 256) * (p->view == WS_VIEW_LEFT ? L->height : R->height);
+        ctx->last_lds = 0;
+    }
+    // everything the marching kernel does not own: border ring, rows past min(h1,h2), or all of it
+    WS_HIP(ctx, launch_generic(ga, s));
+    if (p->subpixel) WS_HIP(ctx, launch_refine(ga, s));
+    return WS_OK;
+}
+
+int out_dims(const ws_params *p, const ws_image *L, const ws_image *R, int *w, int *h)
+{
+    *w = p->view == WS_VIEW_LEFT ? L->width : R->width;
+    *h = p->view == WS_VIEW_LEFT ? L->height : R->height;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int ws_version(void) { return WS_VERSION; }
+
+void ws_params_default(ws_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->view = WS_VIEW_LEFT;
+    p->cost = WS_COST_SSD;
+    p->block_size = 7;
+    p->min_disparity = 0;
+    p->max_disparity = 64;
+    p->smooth_factor = 1.0;
+    p->var_block = 0;
+    p->thres = 19.0;
+    p->subpixel = 0;
+    p->linear_range = 200;
+}
+
+int ws_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ws_create(int device, ws_context **out)
+{
+    if (!out) return WS_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, WS_ERR_HIP, "no HIP device available (%s): this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, WS_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    ws_context *ctx = new (std::nothrow) ws_context();
+    if (!ctx) return WS_ERR_NOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        fail(nullptr, WS_ERR_HIP, "ws_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return WS_ERR_HIP;
+    }
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = ctx;
+    return WS_OK;
+}
+
+void ws_destroy(ws_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+        if (b->p) (void)hipFree(b->p);
+    for (Job &j : ctx->jobs) {
+        if (j.pin_in) (void)hipHostFree(j.pin_in);
+        if (j.pin_out) (void)hipHostFree(j.pin_out);
+        if (j.d_left) (void)hipFree(j.d_left);
+        if (j.d_right) (void)hipFree(j.d_right);
+        if (j.d_out) (void)hipFree(j.d_out);
+        if (j.d_out64) (void)hipFree(j.d_out64);
+    }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *ws_last_error(const ws_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_dev,
+                     const ws_image *right_dev, float *out_dev, int out_stride, void *stream)
+{
+    int rc = check_params(ctx, p, left_dev, right_dev);
+    if (rc != WS_OK) return rc;
+    if (!out_dev) return fail(ctx, WS_ERR_ARG, "null output");
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    return run_device(ctx, p, left_dev, right_dev, out_dev, out_stride, s);
+}
+
+int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
+                   void *out, int out_stride, int out_dtype)
+{
+    int rc = check_params(ctx, p, left, right);
+    if (rc != WS_OK) return rc;
+    if (!out || (out_dtype != WS_OUT_F32 && out_dtype != WS_OUT_F64)) return fail(ctx, WS_ERR_ARG, "bad output");
+    int ow, oh;
+    out_dims(p, left, right, &ow, &oh);
+    if (out_stride < ow) return fail(ctx, WS_ERR_ARG, "out_stride %d < width %d", out_stride, ow);
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
+    if ((rc = ensure(ctx, ctx->d_left, lb * left->height)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_right, rb * right->height)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * oh * 4)) != WS_OK) return rc;
+    WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, s));
+    WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_right.p, rb, right->data, right->stride, rb, right->height, hipMemcpyHostToDevice, s));
+    ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, (int)lb};
+    ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, (int)rb};
+    float *dout = static_cast<float *>(ctx->d_out.p);
+    if ((rc = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) return rc;
+    if (out_dtype == WS_OUT_F32) {
+        WS_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride * 4, dout, (size_t)ow * 4, (size_t)ow * 4, oh, hipMemcpyDeviceToHost, s));
+    } else {
+        if ((rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
+        double *d64 = static_cast<double *>(ctx->d_out64.p);
+        WS_HIP(ctx, launch_widen(dout, ow, d64, ow, ow, oh, s));
+        WS_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride * 8, d64, (size_t)ow * 8, (size_t)ow * 8, oh, hipMemcpyDeviceToHost, s));
+    }
+    WS_HIP(ctx, hipStreamSynchronize(s));
+    return WS_OK;
+}
+
+int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
+                    void *out, int out_stride, int out_dtype)
+{
+    int rc = check_params(ctx, p, left, right);
+    if (rc != WS_OK) return rc;
+    if (!out || (out_dtype != WS_OUT_F32 && out_dtype != WS_OUT_F64)) return fail(ctx, WS_ERR_ARG, "bad output");
+    int ow, oh;
+    out_dims(p, left, right, &ow, &oh);
+    if (out_stride < ow) return fail(ctx, WS_ERR_ARG, "out_stride %d < width %d", out_stride, ow);
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // a free job slot (its buffers are re-used across batches), or a new one
+    Job *job = nullptr;
+    for (Job &j : ctx->jobs) if (!j.busy) { job = &j; break; }
+    if (!job) { ctx->jobs.emplace_back(); job = &ctx->jobs.back(); }
+    const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
+    const size_t in_bytes = lb * left->height + rb * right->height;
+    const size_t esz = out_dtype == WS_OUT_F64 ? 8 : 4;
+    const size_t out_bytes = (size_t)ow * oh * esz;
+    if (in_bytes > job->in_cap) {
+        if (job->pin_in) WS_HIP(ctx, hipHostFree(job->pin_in));
+        if (job->d_left) WS_HIP(ctx, hipFree(job->d_left));
+        job->pin_in = nullptr; job->d_left = nullptr; job->in_cap = 0;
+        WS_HIP(ctx, hipHostMalloc(&job->pin_in, in_bytes, hipHostMallocDefault));
+        WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job->d_left), in_bytes));
+        job->in_cap = in_bytes;
+    }
+    if (out_bytes > job->out_cap) {
+        if (job->pin_out) WS_HIP(ctx, hipHostFree(job->pin_out));
+        if (job->d_out) WS_HIP(ctx, hipFree(job->d_out));
+        if (job->d_out64) WS_HIP(ctx, hipFree(job->d_out64));
+        job->pin_out = nullptr; job->d_out = nullptr; job->d_out64 = nullptr; job->out_cap = 0;
+        WS_HIP(ctx, hipHostMalloc(&job->pin_out, (size_t)ow * oh * 8, hipHostMallocDefault));
+        WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job->d_out), (size_t)ow * oh * 4));
+        WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job->d_out64), (size_t)ow * oh * 8));
+        job->out_cap = (size_t)ow * oh * 8;
+    }
+    job->d_right = job->d_left + lb * left->height;
+    uint8_t *hin = static_cast<uint8_t *>(job->pin_in);
+    for (int y = 0; y < left->height; ++y) memcpy(hin + y * lb, left->data + (size_t)y * left->stride, lb);
+    uint8_t *hin_r = hin + lb * left->height;
+    for (int y = 0; y < right->height; ++y) memcpy(hin_r + y * rb, right->data + (size_t)y * right->stride, rb);
+    WS_HIP(ctx, hipMemcpyAsync(job->d_left, hin, in_bytes, hipMemcpyHostToDevice, s));
+    ws_image dl{job->d_left, left->width, left->height, (int)lb};
+    ws_image dr{job->d_right, right->width, right->height, (int)rb};
+    if ((rc = run_device(ctx, p, &dl, &dr, job->d_out, ow, s)) != WS_OK) return rc;
+    if (out_dtype == WS_OUT_F64) {
+        WS_HIP(ctx, launch_widen(job->d_out, ow, job->d_out64, ow, ow, oh, s));
+        WS_HIP(ctx, hipMemcpyAsync(job->pin_out, job->d_out64, out_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        WS_HIP(ctx, hipMemcpyAsync(job->pin_out, job->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    }
+    job->user_out = out; job->w = ow; job->h = oh; job->out_stride = out_stride; job->dtype = out_dtype;
+    job->busy = true;
+    return WS_OK;
+}
+
+int ws_wait(ws_context *ctx)
+{
+    if (!ctx) return WS_ERR_ARG;
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    WS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (Job &j : ctx->jobs) {
+        if (!j.busy) continue;
+        const size_t esz = j.dtype == WS_OUT_F64 ? 8 : 4;
+        const uint8_t *src = static_cast<const uint8_t *>(j.pin_out);
+        uint8_t *dst = static_cast<uint8_t *>(j.user_out);
+        for (int y = 0; y < j.h; ++y)
+            memcpy(dst + (size_t)y * j.out_stride * esz, src + (size_t)y * j.w * esz, (size_t)j.w * esz);
+        j.busy = false;
+    }
+    return WS_OK;
+}
+
+int ws_timer_begin(ws_context *ctx, void *stream)
+{
+    if (!ctx) return WS_ERR_ARG;
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    WS_HIP(ctx, hipEventRecord(ctx->ev0, stream ? static_cast<hipStream_t>(stream) : ctx->stream));
+    return WS_OK;
+}
+
+int ws_timer_end(ws_context *ctx, void *stream, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return WS_ERR_ARG;
+    WS_HIP(ctx, hipEventRecord(ctx->ev1, stream ? static_cast<hipStream_t>(stream) : ctx->stream));
+    WS_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    WS_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return WS_OK;
+}
+
+int ws_last_launch_info(const ws_context *ctx, char *kernel_name, int name_cap, int *threads,
+                        int *workgroups, int *lds_bytes)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (kernel_name && name_cap > 0) {
+        strncpy(kernel_name, ctx->last_kernel.c_str(), (size_t)name_cap - 1);
+        kernel_name[name_cap - 1] = 0;
+    }
+    if (threads) *threads = ctx->last_threads;
+    if (workgroups) *workgroups = ctx->last_wgs;
+    if (lds_bytes) *lds_bytes = ctx->last_lds;
+    return WS_OK;
+}
+
+int ws_set_tuning(ws_context *ctx, int x_runs_per_tile, int strip_rows, int threads)
+{
+    if (!ctx || x_runs_per_tile < 0 || strip_rows < 0 || threads < 0) return WS_ERR_ARG;
+    ctx->tune_nxr = x_runs_per_tile;
+    ctx->tune_rows = strip_rows;
+    ctx->tune_threads = threads;
+    return WS_OK;
+}
+
+// ---- Middlebury plumbing ---------------------------------------------------------------
+
+void ws_free(void *p) { free(p); }
+
+int ws_pfm_read(const char *path, float **data, int *width, int *height)
+{
+    if (!path || !data || !width || !height) return WS_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return WS_ERR_IO;
+    char tag[8] = {0};
+    int w = 0, h = 0;
+    double scale = 0;
+    // "Pf" = one channel; header fields are whitespace separated, one whitespace byte before data
+    if (fscanf(f, "%7s %d %d %lf", tag, &w, &h, &scale) != 4 || strcmp(tag, "Pf") != 0 || w <= 0 || h <= 0 ||
+        scale == 0) {
+        fclose(f);
+        return WS_ERR_IO;
+    }
+    fgetc(f);
+    float *buf = static_cast<float *>(malloc((size_t)w * h * sizeof(float)));
+    if (!buf) { fclose(f); return WS_ERR_NOMEM; }
+    const uint16_t probe = 1;
+    const bool host_little = *reinterpret_cast<const uint8_t *>(&probe) == 1;
+    const bool file_little = scale < 0;
+    for (int y = h - 1; y >= 0; --y) { // the file stores the bottom row first
+        float *row = buf + (size_t)y * w;
+        if (fread(row, sizeof(float), (size_t)w, f) != (size_t)w) { free(buf); fclose(f); return WS_ERR_IO; }
+        if (host_little != file_little)
+            for (int x = 0; x < w; ++x) {
+                uint32_t v;
+                memcpy(&v, row + x, 4);
+                v = (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+                memcpy(row + x, &v, 4);
+            }
+    }
+    fclose(f);
+    *data = buf; *width = w; *height = h;
+    return WS_OK;
+}
+
+int ws_pfm_write(const char *path, const float *data, int width, int height, int stride)
+{
+    if (!path || !data || width <= 0 || height <= 0 || stride < width) return WS_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return WS_ERR_IO;
+    const uint16_t probe = 1;
+    const bool host_little = *reinterpret_cast<const uint8_t *>(&probe) == 1;
+    fprintf(f, "Pf\n%d %d\n%s\n", width, height, host_little ? "-1.0" : "1.0");
+    for (int y = height - 1; y >= 0; --y)
+        if (fwrite(data + (size_t)y * stride, sizeof(float), (size_t)width, f) != (size_t)width) { fclose(f); return WS_ERR_IO; }
+    return fclose(f) == 0 ? WS_OK : WS_ERR_IO;
+}
+
+static bool parse_cam(const char *line, float m[9])
+{
+    // "cam0=[fx 0 cx; 0 fy cy; 0 0 1]": drop 6 leading characters and the closing bracket,
+    // semicolons become blanks (data_loader.cpp:148-154)
+    std::string s(line);
+    while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+    if (s.size() < 8) return false;
+    s = s.substr(6, s.size() - 7);
+    std::replace(s.begin(), s.end(), ';', ' ');
+    return sscanf(s.c_str(), "%f %f %f %f %f %f %f %f %f", m, m + 1, m + 2, m + 3, m + 4, m + 5, m + 6, m + 7, m + 8) == 9;
+}
+
+int ws_calib_read(const char *path, ws_calib *out)
+{
+    if (!path || !out) return WS_ERR_ARG;
+    FILE *f = fopen(path, "r");
+    if (!f) return WS_ERR_IO;
+    memset(out, 0, sizeof *out);
+    out->doffs = out->baseline = -1.0f;
+    out->width = out->height = out->ndisp = -1;
+    char line[512];
+    int n = 0;
+    bool ok = true;
+    while (fgets(line, sizeof line, f)) {
+        if (n == 0) ok = ok && parse_cam(line, out->cam0);
+        else if (n == 1) ok = ok && parse_cam(line, out->cam1);
+        else {
+            float v;
+            if (sscanf(line, "doffs=%f", &v) == 1) out->doffs = v;
+            else if (sscanf(line, "baseline=%f", &v) == 1) out->baseline = v;
+            else if (sscanf(line, "width=%f", &v) == 1) out->width = (int)v;
+            else if (sscanf(line, "height=%f", &v) == 1) out->height = (int)v;
+            else if (sscanf(line, "ndisp=%f", &v) == 1) out->ndisp = (int)v;
+        }
+        ++n;
+    }
+    fclose(f);
+    return (ok && n >= 2) ? WS_OK : WS_ERR_IO;
+}
+
+int ws_evaldisp(const float *disp, const float *gt, const uint8_t *mask, int width, int height,
+                float badthresh, float maxdisp, int rounddisp, double res[6])
+{
+    if (!disp || !gt || !mask || !res || width <= 0 || height <= 0) return WS_ERR_ARG;
+    int n = 0, bad = 0, invalid = 0;
+    float serr = 0;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const size_t o = (size_t)y * width + x;
+            const float g = gt[o];
+            if (g == INFINITY) continue;                    // unknown (utils.cpp:137)
+            float d = disp[o];
+            const bool valid = d != 0;                      // utils.cpp:140
+            if (valid) d = fmaxf(0.0f, fminf(maxdisp, d));
+            if (valid && rounddisp) d = roundf(d);
+            const float err = fabsf(d - g);
+            if (mask[o] != 255) continue;                   // utils.cpp:146
+            ++n;
+            if (valid) { serr += err; if (err > badthresh) ++bad; }
+            else ++invalid;
+        }
+    res[0] = n;
+    res[1] = (float)(100.0 * bad / n);
+    res[2] = (float)(100.0 * invalid / n);
+    res[3] = (float)(100.0 * (bad + invalid) / n);
+    res[4] = serr / (float)(n - invalid);
+    res[5] = 100.0 * n / ((double)width * height);
+    return WS_OK;
+}
+
+} // extern "C"

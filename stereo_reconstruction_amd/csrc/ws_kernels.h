@@ -1,0 +1,84 @@
+// ws_kernels.h -- launch interface between the C-ABI host code (ws_capi.cpp) and the
+// gfx950 kernels (ws_kernels.hip).  Internal; the public boundary is include/ws_stereo.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wsamd {
+
+// Poison added to a key for an invalid candidate; valid keys stay inside (-2^28, 2^28).
+constexpr int32_t kPoison = 1 << 29;
+constexpr int32_t kValidKeyBound = 1 << 28;
+
+// The "canonical" search every view is reduced to:
+//   outputs live on plane A, candidates d in [d_lo, d_hi] look at plane B column x - d + boff.
+// LEFT  (BlockSearch.cpp:24-86):  A = left,  B = right, window bs x bs centred.
+// RIGHT (BlockSearch.cpp:88-179): A = right, B = left, both mirrored in x so that the
+//   reference's cx = x + d becomes x' - d + (w1 - w2); window (bs-1) x (bs-1).
+struct Canon {
+    int wa, ha, wb, hb;     // plane sizes (pixels)
+    int ww, wh;             // window width / height
+    int wx0, wy0;           // window origin relative to the output pixel
+    int boff;               // B column = x - d + boff
+    int d_lo, d_hi;         // inclusive candidate range
+    int b_lo, b_hi;         // inclusive range of valid B centre columns
+    int ox0, ox1, oy0, oy1; // outputs computed by the marching kernel: [ox0,ox1) x [oy0,oy1)
+    int prefer_large;       // ties: 1 -> largest d wins (left), 0 -> smallest d (right)
+    int mirror;             // canonical x = wa - 1 - original x
+    int fallback_neg;       // no valid candidate: store +x (left) or -x (right), original x
+    int ssd;                // 1 = SSD (NORM_L2), 0 = SAD (NORM_L1)
+};
+
+// Packed planes: one uint32 per pixel (B | G<<8 | R<<16), zero outside the image.
+struct Plane {
+    uint32_t *data;
+    int pitch; // dwords per row
+    int pad;   // plane column = image column + pad
+};
+
+struct MarchLaunch {
+    int x_per_thread, nd_per_thread; // X, ND template choice
+    int nxr, nch;                    // x-runs per tile, d-chunks per tile
+    int threads;                     // workgroup size
+    int tiles, strips, strip_rows;
+    size_t lds_bytes;
+    int max_threads;                 // launch-bounds variant (1024 or 768)
+};
+
+// Which (window, X, ND) instantiations exist.  Returns false if none fits.
+bool march_supported(const Canon &c);
+// Fill the tiling for this problem (tuning values of 0 = automatic).
+bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
+                MarchLaunch *out);
+// Plane geometry (pad / pitch) the plan needs.
+void march_plane_geometry(const Canon &c, const MarchLaunch &m, int *pad_a, int *pitch_a,
+                          int *pad_b, int *pitch_b);
+
+hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror, Plane dst,
+                       hipStream_t s);
+hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, int32_t *bias,
+                       hipStream_t s);
+hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b,
+                        const int32_t *bias, float *out, int out_pitch, hipStream_t s);
+const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
+
+// Brute-force kernels on the original 8-bit images (original coordinates, literal rules).
+struct GenericArgs {
+    const uint8_t *L;
+    const uint8_t *R;
+    int w1, h1, s1, w2, h2, s2;
+    int view, ssd, block_size, min_d, max_d, linear_range;
+    // pixels inside [skip_x0,skip_x1) x [skip_y0,skip_y1) are left to the marching kernel
+    int skip_x0, skip_x1, skip_y0, skip_y1;
+    float *out;
+    int out_pitch;
+};
+hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
+// Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
+hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
+// float32 -> float64 widening for CV_64F outputs
+hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
+                        hipStream_t s);
+
+} // namespace wsamd
