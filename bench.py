@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- Mdisparities/s of the WindowSearch hot path on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (BlockSearch::computeDisparityMapLeft,
+BlockSearch.cpp:24-86, through the C-ABI ws_search_device) over one synthetic
+Middlebury-H-shaped pair that is already resident in HBM: BASELINE.json configs[1]
+= 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0.  With N ranks every rank
+owns its own pair (independent pairs shard with no collective: weak scaling); the
+barrier / all_reduce(MAX) below only brackets the timing.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
+(ws_march_kernel): algorithmic bytes per launch / its average duration measured
+with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
+(oracle/, a port: the reference itself cannot be built here) on a bounded row band
+of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (width, height, block, cost, maxD, seed)
+    "config2": (1500, 1000, 7, "ssd", 256, 2),
+    "config3": (2964, 1988, 9, "sad", 512, 3),
+    "config5": (3840, 2160, 9, "ssd", 1024, 5),
+    "config1": (450, 375, 5, "sad", 64, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU baseline sample")
+    ap.add_argument("--check", action="store_true", help="compare a row band with the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import stereo_reconstruction_amd as ws
+    from stereo_reconstruction_amd.synthetic import make_pair
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
+    left, right, _gt = make_pair(width, height, max_d, seed + rank)
+    dev = torch.device("cuda", local_rank)
+    t_left = torch.from_numpy(left).to(dev)
+    t_right = torch.from_numpy(right).to(dev)
+    t_out = torch.empty((height, width), dtype=torch.float32, device=dev)
+    ctx = ws.WindowSearch(local_rank)
+    params = ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.search_device(params, t_left, t_right, t_out, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    hyps = float(width) * height * max_d          # H*W*D per pair
+    value = hyps * args.steps * world / elapsed / 1e6
+
+    # dominant kernel, timed alone with HIP events on the launch stream
+    kernel_ms = None
+    info = ctx.last_launch()
+    ctx.set_profiling(True)
+    acc = []
+    for _ in range(min(args.steps, 20)):
+        step()
+        acc.append(ctx.last_kernel_ms())
+    ctx.set_profiling(False)
+    kernel_ms = float(np.mean(acc))
+    alg_bytes = 3.0 * height * width + 3.0 * right.shape[0] * right.shape[1] + 4.0 * height * width
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Mdisparities/s (HxWxD / s) on Middlebury-H pairs",
+        "value": round(value, 1),
+        "unit": "Mdisparities/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
+                               % (args.workload, width, height, bs, bs, cost.upper(), max_d),
+                   "pairs_per_step": world, "sharding": "independent pairs, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": info["kernel"], "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes": alg_bytes,
+                     "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "
+                             "VALU-issue bound, see DESIGN.md for the lane-op ceiling"},
+    }
+
+    if args.check and rank == 0:
+        from oracle import oracle
+        y0 = height // 2
+        ref = oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=(y0, y0 + 8),
+                                threads=os.cpu_count() or 1)
+        got = t_out[y0:y0 + 8].cpu().numpy().astype(np.float64)
+        out["check_rows_equal"] = bool(np.array_equal(got, ref[y0:y0 + 8]))
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        half = (bs - 1) // 2
+        rows = (half, min(height - half, half + args.cpu_rows))
+        t0 = time.perf_counter()
+        oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=rows, threads=cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round((rows[1] - rows[0]) * width * max_d / dt / 1e6, 2),
+            "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+            "sample": "rows [%d,%d) of the same pair (%.0f%% of it), oracle/ws_oracle.c row-parallel "
+                      "over %d threads, %.1f s" % (rows[0], rows[1], 100.0 * (rows[1] - rows[0]) / height,
+                                                  cores, dt)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,13 @@ int ws_wait(ws_context *ctx);
 int ws_timer_begin(ws_context *ctx, void *stream);
 int ws_timer_end(ws_context *ctx, void *stream, float *elapsed_ms);
 /*
+ * With profiling on, every ws_search_* call brackets its dominant kernel (the marching
+ * kernel) with a hipEvent pair on the launch stream; ws_last_kernel_ms waits for it and
+ * returns that one launch's duration.  This is what bench.py's `roofline` is computed from.
+ */
+int ws_set_profiling(ws_context *ctx, int enable);
+int ws_last_kernel_ms(ws_context *ctx, float *elapsed_ms);
+/*
  * After a ws_search_* call: the kernel that dominates it and how the path was tiled
  * (name as it appears in a rocprofv3 kernel trace, threads per workgroup, workgroups,
  * dynamic LDS bytes).  For reports; not part of the reference's surface.

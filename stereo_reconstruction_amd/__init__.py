@@ -35,7 +35,8 @@ ERRORS = {-1: "WS_ERR_ARG", -2: "WS_ERR_GEOMETRY", -3: "WS_ERR_UNSUPPORTED", -4:
 # every symbol include/ws_stereo.h declares (tests check the library exports all of them)
 EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_last_error",
            "ws_device_count", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait",
-           "ws_timer_begin", "ws_timer_end", "ws_last_launch_info", "ws_set_tuning",
+           "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
+           "ws_last_launch_info", "ws_set_tuning",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -95,6 +96,8 @@ def load_library(build_if_missing=False):
     lib.ws_wait.argtypes = [vp]
     lib.ws_timer_begin.argtypes = [vp, vp]
     lib.ws_timer_end.argtypes = [vp, vp, P(ctypes.c_float)]
+    lib.ws_set_profiling.argtypes = [vp, ci]
+    lib.ws_last_kernel_ms.argtypes = [vp, P(ctypes.c_float)]
     lib.ws_last_launch_info.argtypes = [vp, ctypes.c_char_p, ci, P(ci), P(ci), P(ci)]
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
@@ -199,6 +202,14 @@ class WindowSearch:
     def timer_end(self, stream=None):
         ms = ctypes.c_float()
         self._check(self._lib.ws_timer_end(self._h, ctypes.c_void_p(stream or 0), ctypes.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, enable):
+        self._check(self._lib.ws_set_profiling(self._h, int(bool(enable))))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(self._lib.ws_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
     def last_launch(self):

@@ -43,7 +43,8 @@ struct ws_context {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    bool profiling = false, kernel_timed = false;
     DevBuf plane_a, plane_b, bias, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
@@ -197,7 +198,12 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, c.mirror, pa, s));
         WS_HIP(ctx, launch_pack(ib->data, ib->width, ib->height, ib->stride, c.mirror, pb, s));
         WS_HIP(ctx, launch_bias(c, m, pb, static_cast<int32_t *>(ctx->bias.p), s));
+        if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         WS_HIP(ctx, launch_march(c, m, pa, pb, static_cast<int32_t *>(ctx->bias.p), out, out_stride, s));
+        if (ctx->profiling) {
+            WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
+            ctx->kernel_timed = true;
+        }
         if (c.mirror) {
             ga.skip_x0 = c.wa - c.ox1; ga.skip_x1 = c.wa - c.ox0;
         } else {
@@ -272,7 +278,8 @@ int ws_create(int device, ws_context **out)
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->evk0)) != hipSuccess || (e = hipEventCreate(&ctx->evk1)) != hipSuccess) {
         fail(nullptr, WS_ERR_HIP, "ws_create: %s", hipGetErrorString(e));
         delete ctx;
         return WS_ERR_HIP;
@@ -299,6 +306,8 @@ void ws_destroy(ws_context *ctx)
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
+    if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -437,6 +446,23 @@ int ws_timer_end(ws_context *ctx, void *stream, float *elapsed_ms)
     WS_HIP(ctx, hipEventRecord(ctx->ev1, stream ? static_cast<hipStream_t>(stream) : ctx->stream));
     WS_HIP(ctx, hipEventSynchronize(ctx->ev1));
     WS_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return WS_OK;
+}
+
+int ws_set_profiling(ws_context *ctx, int enable)
+{
+    if (!ctx) return WS_ERR_ARG;
+    ctx->profiling = enable != 0;
+    ctx->kernel_timed = false;
+    return WS_OK;
+}
+
+int ws_last_kernel_ms(ws_context *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return WS_ERR_ARG;
+    if (!ctx->kernel_timed) return fail(ctx, WS_ERR_ARG, "no marching-kernel launch was timed (ws_set_profiling off, or the generic path ran)");
+    WS_HIP(ctx, hipEventSynchronize(ctx->evk1));
+    WS_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->evk0, ctx->evk1));
     return WS_OK;
 }
 
