@@ -39,6 +39,18 @@ WORKLOADS = {
 }
 
 
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,13 +158,13 @@ def main():
         from oracle import oracle
         y0 = height // 2
         ref = oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=(y0, y0 + 8),
-                                threads=os.cpu_count() or 1)
+                                threads=host_cores())
         got = t_out[y0:y0 + 8].cpu().numpy().astype(np.float64)
         out["check_rows_equal"] = bool(np.array_equal(got, ref[y0:y0 + 8]))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         half = (bs - 1) // 2
         rows = (half, min(height - half, half + args.cpu_rows))
         t0 = time.perf_counter()

@@ -95,6 +95,24 @@ void ws_destroy(ws_context *ctx);
 const char *ws_last_error(const ws_context *ctx);
 int ws_device_count(void);
 
+/*
+ * The argument checks of the search calls without a device: the status a search with these
+ * arguments would return before launching anything (WS_OK, WS_ERR_ARG, WS_ERR_GEOMETRY for
+ * what makes the reference throw, WS_ERR_UNSUPPORTED).  Message via ws_last_error(NULL).
+ */
+int ws_validate(const ws_params *p, const ws_image *left, const ws_image *right);
+
+/* How a search would be tiled on a device with num_cus compute units (0 = 256); host logic only. */
+typedef struct {
+    int marching;                   /* 1: the marching kernel owns the interior; 0: brute force only */
+    int x_per_thread, d_per_thread; /* columns x disparities whose window sums one thread keeps */
+    int x_runs, d_chunks;           /* per workgroup: tile = x_runs*x_per_thread columns, all d */
+    int threads, tiles, strips, strip_rows, lds_bytes;
+    int interior_x0, interior_x1, interior_y0, interior_y1; /* outputs the marching kernel writes */
+} ws_plan_info;
+int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int num_cus,
+            ws_plan_info *out);
+
 /* ---- the hot path ----------------------------------------------------------------- */
 /*
  * Synchronous call on host buffers; replaces

@@ -14,7 +14,9 @@ There is no CPU fallback: if the library is missing or no HIP device answers, th
 raise.  The CPU oracle under oracle/ is test infrastructure and is never imported here.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -34,7 +36,7 @@ ERRORS = {-1: "WS_ERR_ARG", -2: "WS_ERR_GEOMETRY", -3: "WS_ERR_UNSUPPORTED", -4:
 
 # every symbol include/ws_stereo.h declares (tests check the library exports all of them)
 EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_last_error",
-           "ws_device_count", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait",
+           "ws_device_count", "ws_validate", "ws_plan", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
            "ws_last_launch_info", "ws_set_tuning",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_calib_read", "ws_evaldisp"]
@@ -65,7 +67,31 @@ class _Calib(ctypes.Structure):
                 ("width", ctypes.c_int), ("height", ctypes.c_int), ("ndisp", ctypes.c_int)]
 
 
+class _PlanInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "marching", "x_per_thread", "d_per_thread", "x_runs", "d_chunks", "threads", "tiles",
+        "strips", "strip_rows", "lds_bytes", "interior_x0", "interior_x1", "interior_y0",
+        "interior_y1")]
+
+
 _lib = None
+
+
+def _preload_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch-ROCm ships its own libamdhip64.so.7 (same
+    SONAME as /opt/rocm's); if this library pulled in the system copy first, a later
+    `import torch` would start a second HSA runtime and find no device.  So when PyTorch is
+    installed but not imported yet, load the runtime it ships before libws_stereo.so."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
 
 
 def load_library(build_if_missing=False):
@@ -79,6 +105,7 @@ def load_library(build_if_missing=False):
             raise RuntimeError("libws_stereo.so is missing: run `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (the HIP extension is the only compute path)")
         _build.build()
+    _preload_hip_runtime()
     lib = ctypes.CDLL(path)
     P, vp, ci = ctypes.POINTER, ctypes.c_void_p, ctypes.c_int
     lib.ws_version.restype = ci
@@ -90,6 +117,8 @@ def load_library(build_if_missing=False):
     lib.ws_last_error.argtypes = [vp]
     lib.ws_last_error.restype = ctypes.c_char_p
     lib.ws_device_count.restype = ci
+    lib.ws_validate.argtypes = [P(_Params), P(_Image), P(_Image)]
+    lib.ws_plan.argtypes = [P(_Params), P(_Image), P(_Image), ci, P(_PlanInfo)]
     lib.ws_search_host.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, ci]
     lib.ws_search_device.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, vp]
     lib.ws_enqueue_host.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, ci]
@@ -222,6 +251,29 @@ class WindowSearch:
 
     def set_tuning(self, x_runs_per_tile=0, strip_rows=0, threads=0):
         self._check(self._lib.ws_set_tuning(self._h, x_runs_per_tile, strip_rows, threads))
+
+
+def _shape_image(shape):
+    """An image header with a non-null dummy pointer: enough for the device-free checks."""
+    h, w = shape[:2]
+    return _Image(1, w, h, 3 * w)
+
+
+def validate(params, left_shape, right_shape):
+    """Status code the search would return for these arguments (no device needed)."""
+    Li, Ri = _shape_image(left_shape), _shape_image(right_shape)
+    return load_library().ws_validate(ctypes.byref(params), ctypes.byref(Li), ctypes.byref(Ri))
+
+
+def plan(params, left_shape, right_shape, num_cus=256):
+    """Tiling the library would use (host logic only, no device needed)."""
+    Li, Ri = _shape_image(left_shape), _shape_image(right_shape)
+    info = _PlanInfo()
+    rc = load_library().ws_plan(ctypes.byref(params), ctypes.byref(Li), ctypes.byref(Ri), num_cus,
+                                ctypes.byref(info))
+    if rc != 0:
+        raise WsError(rc, load_library().ws_last_error(None).decode())
+    return {n: getattr(info, n) for n, _ in _PlanInfo._fields_}
 
 
 _default_ctx = None

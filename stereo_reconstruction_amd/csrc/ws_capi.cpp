@@ -93,7 +93,6 @@ bool image_ok(const ws_image *im)
 
 int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R)
 {
-    if (!ctx) return WS_ERR_ARG;
     if (!p || !image_ok(L) || !image_ok(R)) return fail(ctx, WS_ERR_ARG, "null or malformed image / params");
     if (p->view != WS_VIEW_LEFT && p->view != WS_VIEW_RIGHT && p->view != WS_VIEW_LINEAR)
         return fail(ctx, WS_ERR_ARG, "unknown view %d", p->view);
@@ -314,9 +313,37 @@ void ws_destroy(ws_context *ctx)
 
 const char *ws_last_error(const ws_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int ws_validate(const ws_params *p, const ws_image *left, const ws_image *right)
+{
+    // same checks as the search calls, without touching a device (message via ws_last_error(NULL))
+    return check_params(nullptr, p, left, right);
+}
+
+int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int num_cus, ws_plan_info *out)
+{
+    if (!out) return WS_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    int rc = check_params(nullptr, p, left, right);
+    if (rc != WS_OK) return rc;
+    Canon c{};
+    MarchLaunch m{};
+    if (make_canon(p, left, right, &c) && march_plan(c, num_cus > 0 ? num_cus : 256, 0, 0, 0, &m)) {
+        out->marching = 1;
+        out->x_per_thread = m.x_per_thread; out->d_per_thread = m.nd_per_thread;
+        out->x_runs = m.nxr; out->d_chunks = m.nch; out->threads = m.threads;
+        out->tiles = m.tiles; out->strips = m.strips; out->strip_rows = m.strip_rows;
+        out->lds_bytes = (int)m.lds_bytes;
+        out->interior_x0 = c.mirror ? c.wa - c.ox1 : c.ox0;
+        out->interior_x1 = c.mirror ? c.wa - c.ox0 : c.ox1;
+        out->interior_y0 = c.oy0; out->interior_y1 = c.oy1;
+    }
+    return WS_OK;
+}
+
 int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_dev,
                      const ws_image *right_dev, float *out_dev, int out_stride, void *stream)
 {
+    if (!ctx) return WS_ERR_ARG;
     int rc = check_params(ctx, p, left_dev, right_dev);
     if (rc != WS_OK) return rc;
     if (!out_dev) return fail(ctx, WS_ERR_ARG, "null output");
@@ -328,6 +355,7 @@ int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_d
 int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
                    void *out, int out_stride, int out_dtype)
 {
+    if (!ctx) return WS_ERR_ARG;
     int rc = check_params(ctx, p, left, right);
     if (rc != WS_OK) return rc;
     if (!out || (out_dtype != WS_OUT_F32 && out_dtype != WS_OUT_F64)) return fail(ctx, WS_ERR_ARG, "bad output");
@@ -361,6 +389,7 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
 int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
                     void *out, int out_stride, int out_dtype)
 {
+    if (!ctx) return WS_ERR_ARG;
     int rc = check_params(ctx, p, left, right);
     if (rc != WS_OK) return rc;
     if (!out || (out_dtype != WS_OUT_F32 && out_dtype != WS_OUT_F64)) return fail(ctx, WS_ERR_ARG, "bad output");

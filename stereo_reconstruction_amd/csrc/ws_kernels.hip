@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
 // ---- instantiation table -----------------------------------------------------------------
 constexpr int kX = 8, kND = 8, kMaxT = 768;
+constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1536)
 
 typedef void (*MarchFn)(const MarchArgs);
 struct MarchEntry {
@@ -426,7 +427,7 @@ bool march_supported(const Canon &c)
     if (c.ox1 <= c.ox0 || c.oy1 <= c.oy0) return false;
     const int dcount = c.d_hi - c.d_lo + 1;
     if (dcount < 1) return false;
-    if (ceil_div(dcount, kND) > kMaxT / 8) return false; // at least 8 x-runs per tile
+    if (ceil_div(dcount, kND) > kMaxT / kMinXRuns) return false;
     // keys must stay inside (-2^28, 2^28): 2 * window * 3 * 255^2 << log2(ND)
     const long long worst = 2LL * c.ww * c.wh * 3 * 255 * 255 * kND;
     return worst < (long long)kValidKeyBound;
@@ -450,7 +451,7 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     if (tune_nxr > 0 && tune_nxr < nxr) nxr = tune_nxr;
     const int need = ceil_div(out_w, kX); // no point in tiles wider than the image
     if (nxr > need) nxr = need;
-    if (nxr < 8) nxr = 8;
+    if (nxr < kMinXRuns) nxr = kMinXRuns;
     if (nxr * m.nch > kMaxT) return false;
     m.nxr = nxr;
     m.threads = round_up(nxr * m.nch, 64);
