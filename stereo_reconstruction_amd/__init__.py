@@ -99,7 +99,7 @@ def load_library(build_if_missing=False):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("WS_STEREO_LIB", _build.LIB)  # override: tuning variants only
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError("libws_stereo.so is missing: run `python -c 'import __graft_entry__ as g; "

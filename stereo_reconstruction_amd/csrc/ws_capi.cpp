@@ -184,21 +184,22 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     bool march = make_canon(p, L, R, &c) &&
                  march_plan(c, ctx->num_cus, ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads, &m);
     if (march) {
-        Plane pa{}, pb{};
-        march_plane_geometry(c, m, &pa.pad, &pa.pitch, &pb.pad, &pb.pitch);
+        Plane pa{}, pb{}, pbi{};
+        march_plane_geometry(c, m, &pa, &pb, &pbi);
         int rc;
         if ((rc = ensure(ctx, ctx->plane_a, (size_t)pa.pitch * c.ha * 4)) != WS_OK) return rc;
         if ((rc = ensure(ctx, ctx->plane_b, (size_t)pb.pitch * c.hb * 4)) != WS_OK) return rc;
-        if ((rc = ensure(ctx, ctx->bias, (size_t)pb.pitch * c.ha * 4)) != WS_OK) return rc;
+        if (c.ssd && (rc = ensure(ctx, ctx->bias, (size_t)pbi.pitch * c.ha * 4)) != WS_OK) return rc;
         pa.data = static_cast<uint32_t *>(ctx->plane_a.p);
         pb.data = static_cast<uint32_t *>(ctx->plane_b.p);
+        pbi.data = static_cast<uint32_t *>(ctx->bias.p);
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
         WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, c.mirror, pa, s));
         WS_HIP(ctx, launch_pack(ib->data, ib->width, ib->height, ib->stride, c.mirror, pb, s));
-        WS_HIP(ctx, launch_bias(c, m, pb, static_cast<int32_t *>(ctx->bias.p), s));
+        if (c.ssd) WS_HIP(ctx, launch_bias(c, m, pb, pbi, s));
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
-        WS_HIP(ctx, launch_march(c, m, pa, pb, static_cast<int32_t *>(ctx->bias.p), out, out_stride, s));
+        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;

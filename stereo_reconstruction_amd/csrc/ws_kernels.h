@@ -52,15 +52,13 @@ bool march_supported(const Canon &c);
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out);
 // Plane geometry (pad / pitch) the plan needs.
-void march_plane_geometry(const Canon &c, const MarchLaunch &m, int *pad_a, int *pitch_a,
-                          int *pad_b, int *pitch_b);
+void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias);
 
 hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror, Plane dst,
                        hipStream_t s);
-hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, int32_t *bias,
-                       hipStream_t s);
-hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b,
-                        const int32_t *bias, float *out, int out_pitch, hipStream_t s);
+hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s);
+hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
+                        float *out, int out_pitch, hipStream_t s);
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 
 // Brute-force kernels on the original 8-bit images (original coordinates, literal rules).

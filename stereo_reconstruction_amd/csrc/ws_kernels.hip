@@ -31,6 +31,9 @@
 
 #include <limits.h>
 
+#include <algorithm>
+#include <type_traits>
+
 namespace wsamd {
 
 // ------------------------------------------------------------------------------------------
@@ -39,6 +42,12 @@ namespace wsamd {
 __host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// dwords per LDS region for a row of n dwords split into nreg regions (+1 quad: runs may over-read)
+__host__ __device__ constexpr int march_region_dwords(int n, int nreg)
+{
+    return 4 * ((((n + 3) >> 2) + nreg - 1) / nreg + 1);
+}
 
 __device__ __forceinline__ uint32_t pix_sad(uint32_t a, uint32_t b, uint32_t acc)
 {
@@ -56,23 +65,39 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const uint8_t *__restrict_
                                                       int stride, int mirror,
                                                       uint32_t *__restrict__ dst, int pitch, int pad)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread = 4 consecutive plane columns (one 16-byte store); pitch is a multiple of 4
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (col >= pitch || y >= h) return;
-    int x = col - pad;
-    uint32_t v = 0;
-    if (x >= 0 && x < w) {
-        if (mirror) x = w - 1 - x;
-        const uint8_t *p = src + (size_t)y * stride + (size_t)x * 3;
-        v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    const int x = col - pad;
+    const uint8_t *row = src + (size_t)y * stride;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (!mirror && x >= 0 && x + 3 < w && ((reinterpret_cast<uintptr_t>(row) + 3 * (size_t)x) & 3) == 0) {
+        // 12 bytes = 3 aligned dwords = 4 BGR pixels
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * (size_t)x);
+        const uint32_t a = p[0], b = p[1], c = p[2];
+        v[0] = a & 0xffffffu;
+        v[1] = (a >> 24) | ((b & 0xffffu) << 8);
+        v[2] = (b >> 16) | ((c & 0xffu) << 16);
+        v[3] = c >> 8;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int xs = x + k;
+            if (xs >= 0 && xs < w) {
+                if (mirror) xs = w - 1 - xs;
+                const uint8_t *p = row + (size_t)xs * 3;
+                v[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            }
+        }
     }
-    dst[(size_t)y * pitch + col] = v;
+    *reinterpret_cast<uint4 *>(dst + (size_t)y * pitch + col) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror, Plane dst,
                        hipStream_t s)
 {
-    dim3 grid(ceil_div(dst.pitch, 256), h);
+    dim3 grid(ceil_div(dst.pitch / 4, 256), h);
     hipLaunchKernelGGL(ws_pack_kernel, grid, dim3(256), 0, s, src, w, h, stride, mirror, dst.data,
                        dst.pitch, dst.pad);
     return hipGetLastError();
@@ -83,31 +108,47 @@ hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror,
 // ------------------------------------------------------------------------------------------
 struct BiasArgs {
     const uint32_t *B;
-    int pitch, pad;
+    int pitch_b, pad_b; // the packed target plane
+    int pitch, pad;     // the bias plane (own padding: its row copies must start 16-byte aligned)
     int ww, wh, wx0, wy0;
     int b_lo, b_hi, oy0, oy1;
     int ssd, shift;
     int32_t *bias;
 };
 
+constexpr int kBiasRows = 8;  // rows per thread: the vertical box sum slides down this many rows
+
+__device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww)
+{
+    uint32_t acc = 0;
+    for (int wx = 0; wx < ww; ++wx) acc = pix_dot(row[wx], row[wx], acc);
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = g.oy0 + blockIdx.y;
-    if (col >= g.pitch || y >= g.oy1) return;
+    const int y0 = g.oy0 + blockIdx.y * kBiasRows;
+    const int y1 = min(y0 + kBiasRows, g.oy1);
+    if (col >= g.pitch || y0 >= y1) return;
     const int xb = col - g.pad;
-    int32_t v = kPoison;
-    if (xb >= g.b_lo && xb <= g.b_hi) {
-        uint32_t acc = 0;
-        if (g.ssd) {
-            for (int wy = 0; wy < g.wh; ++wy) {
-                const uint32_t *row = g.B + (size_t)(y + g.wy0 + wy) * g.pitch + (col + g.wx0);
-                for (int wx = 0; wx < g.ww; ++wx) acc = pix_dot(row[wx], row[wx], acc);
-            }
-        }
-        v = (int32_t)(acc << g.shift);
+    int32_t *dst = g.bias + (size_t)y0 * g.pitch + col;
+    if (xb < g.b_lo || xb > g.b_hi || !g.ssd) {
+        const int32_t v = (xb < g.b_lo || xb > g.b_hi) ? kPoison : 0;
+        for (int y = y0; y < y1; ++y, dst += g.pitch) *dst = v;
+        return;
     }
-    g.bias[(size_t)y * g.pitch + col] = v;
+    // box sum of squared target pixels: horizontal sums per row, vertical sum slid down the strip
+    const uint32_t *top = g.B + (size_t)(y0 + g.wy0) * g.pitch_b + (xb + g.pad_b + g.wx0);
+    uint32_t acc = 0;
+    for (int wy = 0; wy < g.wh; ++wy) acc += row_square_sum(top + (size_t)wy * g.pitch_b, g.ww);
+    for (int y = y0; y < y1; ++y, dst += g.pitch) {
+        *dst = (int32_t)(acc << g.shift);
+        if (y + 1 < y1) {
+            acc += row_square_sum(top + (size_t)g.wh * g.pitch_b, g.ww) - row_square_sum(top, g.ww);
+            top += g.pitch_b;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -116,77 +157,119 @@ __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
 struct MarchArgs {
     const uint32_t *A;
     const uint32_t *B;
-    const int32_t *bias;
+    const int32_t *bias; // SSD only
     float *out;
-    int pitch_a, pad_a, pitch_b, pad_b, out_pitch;
+    int pitch_a, pad_a, pitch_b, pad_b, pitch_bi, pad_bi, out_pitch;
     int wa;
     int nxr, nch;
     int wx0, wy0, boff;
-    int d_lo, d_hi;
+    int d_lo, d_hi, b_lo, b_hi;
     int ox0, ox1, oy0, oy1;
     int strip_rows;
     int prefer_large, mirror, fallback_neg;
+    int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
 };
 
-// N consecutive dwords from a 16-byte aligned LDS address: ds_read_b128 for the quads.
-template <int N>
-__device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *src)
+// LDS row layout.  A thread reads runs of consecutive pixels starting at column X*r; with a
+// plain row-major row the 16 lanes that share a ds_read_b128 cycle sit 4*X bytes apart and fall
+// on every (X/4)-th bank group only.  So a row is stored as NREG = X/4 regions: region j holds
+// the quads (16-byte groups of 4 pixels) whose index is j mod NREG, densely.  Lane r's m-th quad
+// is then quad r + m/NREG of region m%NREG: consecutive lanes read consecutive 16-byte slots and
+// every read is conflict free.  `ro` = dwords per region.
+template <int NREG>
+__device__ __forceinline__ int lds_phys(int q, int ro)
 {
-    constexpr int Q = N / 4;
+    const int quad = q >> 2;
+    return (quad % NREG) * ro + (quad / NREG) * 4 + (q & 3);
+}
+
+// N consecutive logical dwords starting at a quad this thread's run starts with
+// (base = row + 4 * first quad index inside region 0).
+template <int N, int NREG>
+__device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *base, int ro)
+{
+    constexpr int Q = (N + 3) / 4;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
-        dst[4 * q + 0] = v.x;
-        dst[4 * q + 1] = v.y;
-        dst[4 * q + 2] = v.z;
-        dst[4 * q + 3] = v.w;
+    for (int m = 0; m < Q; ++m) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + (m % NREG) * ro + (m / NREG) * 4);
+        if (4 * m + 0 < N) dst[4 * m + 0] = v.x;
+        if (4 * m + 1 < N) dst[4 * m + 1] = v.y;
+        if (4 * m + 2 < N) dst[4 * m + 2] = v.z;
+        if (4 * m + 3 < N) dst[4 * m + 3] = v.w;
     }
+}
+
+// Asynchronous HBM -> LDS copy of one row (n dwords, 16-byte aligned source) into the region
+// layout, by the whole workgroup: global_load_lds_dwordx4, no VGPR staging.  The LDS address of
+// an LDS-DMA is wave-uniform base + lane * 16, so consecutive lanes fill consecutive quads of one
+// region and each lane fetches the quad that belongs there (the source address carries the
+// permutation).  Completion is covered by the vmcnt(0) hipcc places before the barrier.
+template <int NREG>
+__device__ __forceinline__ void stage_row_async(uint32_t *row, int ro, const uint32_t *gsrc, int n,
+                                                int tid, int nt)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    const int lane = tid & 63;
+    const int nquads = (n + 3) >> 2;
 #pragma unroll
-    for (int k = 4 * Q; k < N; ++k) dst[k] = src[k];
+    for (int j = 0; j < NREG; ++j) {
+        const int nidx = (nquads - j + NREG - 1) / NREG; // quads of this region
+        for (int idx = tid; idx < nidx; idx += nt)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + 4 * (idx * NREG + j)),
+                                             (lds_void *)(row + j * ro + 4 * (idx - lane)), 16, 0, 0);
+    }
 }
 
 // One row entering (SIGN=+1) or leaving (SIGN=-1) the window of every (column, disparity) this
-// thread owns.  V holds   SAD: (window sum << SH) + tag      SSD: tag - (2 * cross sum << LT).
-// With KEY the candidate keys  bias[xb] + V  are folded into best[] (signed min; ties go to the
-// smaller tag, i.e. to the disparity the reference's strict '<' would have kept).
+// thread owns.
+//   SAD: V = (window sum << shift) + global tie tag          key = V
+//   SSD: V = local tie tag - (2 * cross sum << LT)           key = bias[xb] + V
+//        (bias = box sum of the squared target pixels << LT, or poison for an invalid centre)
+// With KEY the candidate keys are folded into best[] (signed min; equal costs go to the smaller
+// tag, i.e. to the disparity the reference's strict '<' keeps).
 template <int X, int ND, int WW, bool SSD, int SIGN, bool KEY>
 __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X],
-                                          const uint32_t *rowA, const uint32_t *rowB,
-                                          const int32_t *rowBias)
+                                          const uint32_t *runA, int ro_a, const uint32_t *runB,
+                                          int ro_b, const int32_t *runBias, int ro_bi, int shift)
 {
+    constexpr int NREG = X / 4;
     constexpr int NA = X + WW - 1;
     constexpr int NB = NA + ND - 1;
     constexpr int NBI = X + ND - 1;
-    constexpr int LT = ilog2c(ND);
-    constexpr int SH = SSD ? LT + 1 : LT;
     // SAD accumulates +cost, SSD accumulates -2*cross: flip the sign of the update for SSD
     constexpr bool ADD = ((SIGN > 0) != SSD);
 
     uint32_t pa[NA], pb[NB];
-    lds_run<NA>(pa, rowA);
-    lds_run<NB>(pb, rowB);
+    lds_run<NA, NREG>(pa, runA, ro_a);
+    lds_run<NB, NREG>(pb, runB, ro_b);
     uint32_t bi[NBI];
-    if (KEY) lds_run<NBI>(bi, reinterpret_cast<const uint32_t *>(rowBias));
+    if constexpr (KEY && SSD) lds_run<NBI, NREG>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
 
+    // two disparities at a time: two independent prefix chains interleave in the issue stream
+    // (a v_dot4 needs a wait state before its result can feed the next v_dot4's accumulator)
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
-        uint32_t S[NA];
-        uint32_t s = 0;
+    for (int j = 0; j < ND; j += 2) {
+        uint32_t S0[NA], S1[NA];
+        uint32_t s0 = 0, s1 = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const uint32_t b = pb[i - j + ND - 1];
-            s = SSD ? pix_dot(pa[i], b, s) : pix_sad(pa[i], b, s);
-            S[i] = s;
+            const uint32_t b0 = pb[i - j + ND - 1], b1 = pb[i - j + ND - 2];
+            s0 = SSD ? pix_dot(pa[i], b0, s0) : pix_sad(pa[i], b0, s0);
+            s1 = SSD ? pix_dot(pa[i], b1, s1) : pix_sad(pa[i], b1, s1);
+            S0[i] = s0;
+            S1[i] = s1;
         }
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-            const uint32_t hi = S[x + WW - 1];
-            const uint32_t lo = x ? S[x - 1] : 0u;
-            const uint32_t w = ADD ? hi - lo : lo - hi;
-            V[x][j] = (int32_t)((w << SH) + (uint32_t)V[x][j]);
-            if (KEY) {
-                const int32_t key = (int32_t)bi[x - j + ND - 1] + V[x][j];
-                best[x] = min(best[x], key);
+            const uint32_t w0 = ADD ? S0[x + WW - 1] - (x ? S0[x - 1] : 0u) : (x ? S0[x - 1] : 0u) - S0[x + WW - 1];
+            const uint32_t w1 = ADD ? S1[x + WW - 1] - (x ? S1[x - 1] : 0u) : (x ? S1[x - 1] : 0u) - S1[x + WW - 1];
+            V[x][j] = (int32_t)((w0 << shift) + (uint32_t)V[x][j]);
+            V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
+            if constexpr (KEY) {
+                const int32_t k0 = SSD ? (int32_t)bi[x - j + ND - 1] + V[x][j] : V[x][j];
+                const int32_t k1 = SSD ? (int32_t)bi[x - j + ND - 2] + V[x][j + 1] : V[x][j + 1];
+                best[x] = min(best[x], min(k0, k1));
             }
         }
     }
@@ -195,9 +278,12 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
 template <int X, int ND, int WW, int WH, bool SSD, int MAXT>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
+    static_assert(X % 4 == 0 && ND % X == 0 && ND % 2 == 0, "run starts must stay region aligned");
+    constexpr int NREG = X / 4;
     constexpr int LT = ilog2c(ND);
     constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
-    constexpr int PA = 2, PB = 3, PBI = 2; // prefetch registers per thread
+    typedef typename std::conditional<SSD, unsigned long long, int32_t>::type slot_t;
+    const slot_t kEmpty = SSD ? (slot_t)~0ull : (slot_t)INT_MAX;
 
     extern __shared__ uint4 ws_smem4[];
     uint32_t *smem = reinterpret_cast<uint32_t *>(ws_smem4);
@@ -205,11 +291,13 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int NT = blockDim.x, tid = threadIdx.x;
     const int tx = g.nxr * X, dt = g.nch * ND;
     const int n_a = tx + WW - 1, n_b = tx + WW + dt - 2, n_bi = tx + dt - 1;
-    const int a_w = (n_a + 3) & ~3, b_w = (n_b + 3) & ~3, bi_w = (n_bi + 3) & ~3;
+    const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREG);
+    const int ro_bi = SSD ? march_region_dwords(n_bi, NREG) : 0;
+    const int a_w = NREG * ro_a, b_w = NREG * ro_b, bi_w = NREG * ro_bi;
     uint32_t *ringA = smem;
     uint32_t *ringB = ringA + NR * a_w;
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(biasr + 2 * bi_w);
+    slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
 
     const int tile_x0 = g.ox0 + blockIdx.x * tx;
     const int ys = g.oy0 + blockIdx.y * g.strip_rows;
@@ -219,88 +307,94 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int dhi_t = g.d_lo + dt - 1;
     const uint32_t *gA = g.A + (tile_x0 + g.wx0 + g.pad_a);
     const uint32_t *gB = g.B + (tile_x0 + g.wx0 + g.boff - dhi_t + g.pad_b);
-    const int32_t *gBi = g.bias + (tile_x0 + g.boff - dhi_t + g.pad_b);
+    const uint32_t *gBi = SSD ? reinterpret_cast<const uint32_t *>(g.bias) + (tile_x0 + g.boff - dhi_t + g.pad_bi) : nullptr;
 
-    for (int k = tid; k < 2 * tx; k += NT) slots[k] = ~0ull;
+    for (int k = tid; k < 2 * tx; k += NT) slots[k] = kEmpty;
 
     const int r = tid % g.nxr, c = tid / g.nxr;
     const bool worker = c < g.nch;
-    const int lb0 = r * X + (g.nch - 1 - (worker ? c : 0)) * ND;
+    // run starts, in quads of region 0: A at column X*r, B / bias at X*r + ND*(nch-1-c)
+    const int ia = 4 * r;
+    const int ib = 4 * (r + (ND / X) * (g.nch - 1 - (worker ? c : 0)));
     const int d0 = g.d_lo + c * ND; // first disparity of this thread's chunk
+    const int shift = SSD ? LT + 1 : g.tag_bits;
+    // global tie tag of local tag jt is ctag + jt (SSD merge)
+    const int ctag = g.prefer_large ? g.d_hi - d0 - (ND - 1) : d0 - g.d_lo;
 
     int32_t V[X][ND];
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-        const int tag = g.prefer_large ? (ND - 1 - j) : j;
-        const int32_t init = (d0 + j <= g.d_hi) ? tag : (kPoison + tag);
+        const int d = d0 + j;
+        if constexpr (SSD) {
+            // local tag: the preferred disparity of a tie gets the smaller tag
+            const int tag = g.prefer_large ? (ND - 1 - j) : j;
+            const int32_t init = (d <= g.d_hi) ? tag : (kPoison + tag);
 #pragma unroll
-        for (int x = 0; x < X; ++x) V[x][j] = init;
+            for (int x = 0; x < X; ++x) V[x][j] = init;
+        } else {
+            // global tag; both validity rules (d range, target centre range) fold into V
+            const int tag = g.prefer_large ? g.d_hi - d : d - g.d_lo;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                const int xb = tile_x0 + r * X + x - d + g.boff;
+                V[x][j] = (d <= g.d_hi && xb >= g.b_lo && xb <= g.b_hi) ? tag : kPoison;
+            }
+        }
     }
 
     const int ra0 = ys + g.wy0; // first window row of the first output row
     const int nsteps = (ye - ys) + WH - 1;
 
     // prologue: row ra0 (and the bias row of step 0 when the window is one row high)
-    for (int k = tid; k < n_a; k += NT) ringA[k] = gA[(size_t)ra0 * g.pitch_a + k];
-    for (int k = tid; k < n_b; k += NT) ringB[k] = gB[(size_t)ra0 * g.pitch_b + k];
-    if (WH == 1)
-        for (int k = tid; k < n_bi; k += NT) biasr[k] = gBi[(size_t)ys * g.pitch_b + k];
+    stage_row_async<NREG>(ringA, ro_a, gA + (size_t)ra0 * g.pitch_a, n_a, tid, NT);
+    stage_row_async<NREG>(ringB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
+    if (SSD && WH == 1)
+        stage_row_async<NREG>(reinterpret_cast<uint32_t *>(biasr), ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
     __syncthreads();
 
-    int add_slot = 0;       // ring slot of the row entering at this step   (a     mod NR)
-    int sub_slot = 2 % NR;  // ring slot of the row leaving at this step    (a-WH  mod NR)
-    for (int a = 0; a < nsteps; ++a) {
+    int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
+    int sub_slot = 2 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
+    // image row of the output flushed at step a (row ys + a - WH) sits in slot (a - WH - wy0) mod NR
+    int out_slot = ((-WH - g.wy0) % NR + NR) % NR;
+    for (int a = 0; a <= nsteps; ++a) {
         const int oi = a - (WH - 1); // output row index inside the strip produced by this step
 
-        // 1. hand the row finished in the previous step to HBM
+        // 1. hand the row finished in the previous step to HBM (a == nsteps: only this)
         if (oi >= 1) {
             const int y = ys + oi - 1;
-            unsigned long long *sl = slots + ((oi - 1) & 1) * tx;
+            slot_t *sl = slots + ((oi - 1) & 1) * tx;
+            const uint32_t *rowA = ringA + out_slot * a_w;
             for (int k = tid; k < tx; k += NT) {
-                const unsigned long long key = sl[k];
-                sl[k] = ~0ull;
+                const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r]
+                const slot_t key = sl[si];
+                sl[si] = kEmpty;
                 const int x = tile_x0 + k;
                 if (x < g.ox1) {
                     const int xo = g.mirror ? g.wa - 1 - x : x;
                     float val;
-                    if (key == ~0ull) {
+                    if (key == kEmpty) {
                         val = g.fallback_neg ? -(float)xo : (float)xo;
                     } else {
-                        const int gtag = (int)(uint32_t)key;
+                        const int gtag = SSD ? (int)(uint32_t)key : ((int)key & ((1 << g.tag_bits) - 1));
                         val = (float)(g.prefer_large ? g.d_hi - gtag : g.d_lo + gtag);
                     }
-                    if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] == 0u) val = 0.0f; // black pixel
+                    // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
+                    if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == 0u) val = 0.0f;
                     g.out[(size_t)y * g.out_pitch + xo] = val;
                 }
             }
         }
+        if (a == nsteps) break;
 
-        // 2. issue the loads of the next step now; they land in LDS after the arithmetic
-        const bool more = a + 1 < nsteps;
-        const bool more_bias = more && (oi + 1 >= 0);
-        uint32_t fa[PA], fb[PB];
-        int32_t fbi[PBI];
-        if (more) {
-            const uint32_t *srcA = gA + (size_t)(ra0 + a + 1) * g.pitch_a;
-            const uint32_t *srcB = gB + (size_t)(ra0 + a + 1) * g.pitch_b;
-#pragma unroll
-            for (int q = 0; q < PA; ++q) {
-                const int k = tid + q * NT;
-                fa[q] = k < n_a ? srcA[k] : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < PB; ++q) {
-                const int k = tid + q * NT;
-                fb[q] = k < n_b ? srcB[k] : 0u;
-            }
-        }
-        if (more_bias) {
-            const int32_t *srcBi = gBi + (size_t)(ys + oi + 1) * g.pitch_b;
-#pragma unroll
-            for (int q = 0; q < PBI; ++q) {
-                const int k = tid + q * NT;
-                fbi[q] = k < n_bi ? srcBi[k] : 0;
-            }
+        // 2. start the copy of the next step's rows into the ring slot nobody reads this step
+        int nxt_slot = add_slot + 1;
+        if (nxt_slot == NR) nxt_slot = 0;
+        if (a + 1 < nsteps) {
+            stage_row_async<NREG>(ringA + nxt_slot * a_w, ro_a, gA + (size_t)(ra0 + a + 1) * g.pitch_a, n_a, tid, NT);
+            stage_row_async<NREG>(ringB + nxt_slot * b_w, ro_b, gB + (size_t)(ra0 + a + 1) * g.pitch_b, n_b, tid, NT);
+            if (SSD && oi + 1 >= 0)
+                stage_row_async<NREG>(reinterpret_cast<uint32_t *>(biasr + ((oi + 1) & 1) * bi_w), ro_bi,
+                                      gBi + (size_t)(ys + oi + 1) * g.pitch_bi, n_bi, tid, NT);
         }
 
         // 3. arithmetic
@@ -309,95 +403,52 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 #pragma unroll
             for (int x = 0; x < X; ++x) best[x] = INT_MAX;
             if (a >= WH)
-                march_row<X, ND, WW, SSD, -1, false>(V, best, ringA + sub_slot * a_w + r * X,
-                                                     ringB + sub_slot * b_w + lb0, nullptr);
+                march_row<X, ND, WW, SSD, -1, false>(V, best, ringA + sub_slot * a_w + ia, ro_a,
+                                                     ringB + sub_slot * b_w + ib, ro_b, nullptr, 0, shift);
             if (oi >= 0) {
-                march_row<X, ND, WW, SSD, +1, true>(V, best, ringA + add_slot * a_w + r * X,
-                                                    ringB + add_slot * b_w + lb0,
-                                                    biasr + (oi & 1) * bi_w + lb0);
-                unsigned long long *sl = slots + (oi & 1) * tx + r * X;
+                march_row<X, ND, WW, SSD, +1, true>(V, best, ringA + add_slot * a_w + ia, ro_a,
+                                                    ringB + add_slot * b_w + ib, ro_b,
+                                                    biasr + (oi & 1) * bi_w + ib, ro_bi, shift);
+                slot_t *sl = slots + (oi & 1) * tx + r;
 #pragma unroll
                 for (int x = 0; x < X; ++x) {
                     const int32_t bk = best[x];
-                    const int32_t t = bk >> LT;
-                    if (t < (kValidKeyBound >> LT)) {
-                        const int jt = bk & (ND - 1);
-                        const int d = d0 + (g.prefer_large ? ND - 1 - jt : jt);
-                        const uint32_t gtag = (uint32_t)(g.prefer_large ? g.d_hi - d : d - g.d_lo);
-                        const unsigned long long key =
-                            ((unsigned long long)((uint32_t)t ^ 0x80000000u) << 32) | gtag;
-                        atomicMin(sl + x, key); // ds_min_u64
+                    if constexpr (SSD) {
+                        const int32_t t = bk >> LT;
+                        if (t < (kValidKeyBound >> LT)) {
+                            const uint32_t gtag = (uint32_t)(ctag + (bk & (ND - 1)));
+                            const unsigned long long key =
+                                ((unsigned long long)((uint32_t)t ^ 0x80000000u) << 32) | gtag;
+                            atomicMin(sl + x * g.nxr, key); // ds_min_u64, lanes on consecutive slots
+                        }
+                    } else {
+                        if (bk < kValidKeyBound) atomicMin(sl + x * g.nxr, bk); // ds_min_i32
                     }
                 }
             } else {
-                march_row<X, ND, WW, SSD, +1, false>(V, best, ringA + add_slot * a_w + r * X,
-                                                     ringB + add_slot * b_w + lb0, nullptr);
+                march_row<X, ND, WW, SSD, +1, false>(V, best, ringA + add_slot * a_w + ia, ro_a,
+                                                     ringB + add_slot * b_w + ib, ro_b, nullptr, 0, shift);
             }
         }
 
-        // 4. land the prefetched row in the ring slot nobody reads during this step
-        int nxt_slot = add_slot + 1;
-        if (nxt_slot == NR) nxt_slot = 0;
-        if (more) {
-            uint32_t *dstA = ringA + nxt_slot * a_w;
-            uint32_t *dstB = ringB + nxt_slot * b_w;
-#pragma unroll
-            for (int q = 0; q < PA; ++q) {
-                const int k = tid + q * NT;
-                if (k < n_a) dstA[k] = fa[q];
-            }
-#pragma unroll
-            for (int q = 0; q < PB; ++q) {
-                const int k = tid + q * NT;
-                if (k < n_b) dstB[k] = fb[q];
-            }
-            // tiles too wide for the prefetch registers: finish synchronously
-            const uint32_t *srcA = gA + (size_t)(ra0 + a + 1) * g.pitch_a;
-            const uint32_t *srcB = gB + (size_t)(ra0 + a + 1) * g.pitch_b;
-            for (int k = tid + PA * NT; k < n_a; k += NT) dstA[k] = srcA[k];
-            for (int k = tid + PB * NT; k < n_b; k += NT) dstB[k] = srcB[k];
-        }
-        if (more_bias) {
-            int32_t *dstBi = biasr + ((oi + 1) & 1) * bi_w;
-#pragma unroll
-            for (int q = 0; q < PBI; ++q) {
-                const int k = tid + q * NT;
-                if (k < n_bi) dstBi[k] = fbi[q];
-            }
-            const int32_t *srcBi = gBi + (size_t)(ys + oi + 1) * g.pitch_b;
-            for (int k = tid + PBI * NT; k < n_bi; k += NT) dstBi[k] = srcBi[k];
-        }
-        __syncthreads();
+        __syncthreads(); // also waits for the asynchronous row copies (vmcnt(0))
         add_slot = nxt_slot;
         if (++sub_slot == NR) sub_slot = 0;
-    }
-
-    // last row of the strip
-    {
-        const int oi = nsteps - 1 - (WH - 1);
-        const int y = ys + oi;
-        unsigned long long *sl = slots + (oi & 1) * tx;
-        for (int k = tid; k < tx; k += NT) {
-            const unsigned long long key = sl[k];
-            const int x = tile_x0 + k;
-            if (x < g.ox1) {
-                const int xo = g.mirror ? g.wa - 1 - x : x;
-                float val;
-                if (key == ~0ull) {
-                    val = g.fallback_neg ? -(float)xo : (float)xo;
-                } else {
-                    const int gtag = (int)(uint32_t)key;
-                    val = (float)(g.prefer_large ? g.d_hi - gtag : g.d_lo + gtag);
-                }
-                if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] == 0u) val = 0.0f;
-                g.out[(size_t)y * g.out_pitch + xo] = val;
-            }
-        }
+        if (++out_slot == NR) out_slot = 0;
     }
 }
 
 // ---- instantiation table -----------------------------------------------------------------
-constexpr int kX = 8, kND = 8, kMaxT = 768;
+#ifndef WS_X
+#define WS_X 8
+#endif
+#ifndef WS_ND
+#define WS_ND 8
+#endif
+#ifndef WS_MAXT
+#define WS_MAXT 512
+#endif
+constexpr int kX = WS_X, kND = WS_ND, kMaxT = WS_MAXT; // build-time tuning (tools/variants.py)
 constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1536)
 
 typedef void (*MarchFn)(const MarchArgs);
@@ -421,6 +472,13 @@ static const MarchEntry *find_march(const Canon &c)
     return nullptr;
 }
 
+static int tag_bits_for(const Canon &c)
+{
+    int bits = 1;
+    while ((1 << bits) < c.d_hi - c.d_lo + 1) ++bits;
+    return bits;
+}
+
 bool march_supported(const Canon &c)
 {
     if (!find_march(c)) return false;
@@ -428,8 +486,10 @@ bool march_supported(const Canon &c)
     const int dcount = c.d_hi - c.d_lo + 1;
     if (dcount < 1) return false;
     if (ceil_div(dcount, kND) > kMaxT / kMinXRuns) return false;
-    // keys must stay inside (-2^28, 2^28): 2 * window * 3 * 255^2 << log2(ND)
-    const long long worst = 2LL * c.ww * c.wh * 3 * 255 * 255 * kND;
+    // keys must stay inside (-2^28, 2^28)
+    //   SSD: (2 * cross sum) << log2(ND)        SAD: window sum << tag bits
+    const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * 255 * 255 * kND
+                                  : ((long long)c.ww * c.wh * 3 * 255) << tag_bits_for(c);
     return worst < (long long)kValidKeyBound;
 }
 
@@ -475,41 +535,52 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     m.strip_rows = ceil_div(out_h, strips);
     m.strips = ceil_div(out_h, m.strip_rows);
     const int dt = m.nch * kND;
-    const int a_w = round_up(tx + c.ww - 1, 4), b_w = round_up(tx + c.ww + dt - 2, 4),
-              bi_w = round_up(tx + dt - 1, 4);
+    const int nreg = kX / 4;
+    const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
+              b_w = nreg * march_region_dwords(tx + c.ww + dt - 2, nreg),
+              bi_w = nreg * march_region_dwords(tx + dt - 1, nreg);
     const int nr = c.wh + 2;
-    m.lds_bytes = (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8;
+    m.lds_bytes = c.ssd ? (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8
+                        : (size_t)(nr * a_w + nr * b_w) * 4 + (size_t)2 * tx * 4;
     if (m.lds_bytes > 160 * 1024) return false;
     *out = m;
     return true;
 }
 
-void march_plane_geometry(const Canon &c, const MarchLaunch &m, int *pad_a, int *pitch_a,
-                          int *pad_b, int *pitch_b)
+static int aligned_pad(int base)
+{
+    // smallest pad >= max(0, -base) that puts column `base` of the image on a 16-byte boundary
+    int pad = base < 0 ? -base : 0;
+    while (((base + pad) & 3) != 0) ++pad;
+    return pad;
+}
+
+void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias)
 {
     const int tx = m.nxr * m.x_per_thread, dt = m.nch * m.nd_per_thread;
     const int dhi_t = c.d_lo + dt - 1;
-    // A columns touched: [ox0 + wx0, ox0 + tiles*tx + ww - 1 + wx0)
-    int lo_a = c.ox0 + c.wx0, hi_a = c.ox0 + m.tiles * tx + c.ww - 1 + c.wx0;
-    if (lo_a > 0) lo_a = 0;
-    if (hi_a < c.wa) hi_a = c.wa;
-    *pad_a = round_up(-lo_a, 4);
-    *pitch_a = round_up(hi_a + *pad_a, 64);
-    // B columns touched: from ox0 + wx0 + boff - dhi_t (also the bias rows, without wx0)
-    int lo_b = c.ox0 + c.wx0 + c.boff - dhi_t;
-    int hi_b = c.ox0 + (m.tiles - 1) * tx + c.boff - dhi_t + (tx + c.ww + dt - 2) + (c.wx0 > 0 ? c.wx0 : 0);
-    if (lo_b > 0) lo_b = 0;
-    if (hi_b < c.wb) hi_b = c.wb;
-    *pad_b = round_up(-lo_b, 4);
-    *pitch_b = round_up(hi_b + *pad_b + 4, 64);
+    const int n_a = tx + c.ww - 1, n_b = tx + c.ww + dt - 2, n_bi = tx + dt - 1;
+    // first column each tile row copy starts at (tile 0); tiles advance by tx (a multiple of 8)
+    const int base_a = c.ox0 + c.wx0;
+    const int base_b = c.ox0 + c.wx0 + c.boff - dhi_t;
+    const int base_bi = c.ox0 + c.boff - dhi_t;
+    const int last = (m.tiles - 1) * tx;
+    a->pad = aligned_pad(base_a);
+    a->pitch = round_up(std::max(base_a + last + round_up(n_a, 4), c.wa) + a->pad + 4, 64);
+    b->pad = aligned_pad(base_b);
+    b->pitch = round_up(std::max(base_b + last + round_up(n_b, 4), c.wb) + b->pad + 4, 64);
+    bias->pad = aligned_pad(base_bi);
+    bias->pitch = round_up(base_bi + last + round_up(n_bi, 4) + bias->pad + 4, 64);
 }
 
-hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, int32_t *bias, hipStream_t s)
+hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s)
 {
     BiasArgs g{};
     g.B = b.data;
-    g.pitch = b.pitch;
-    g.pad = b.pad;
+    g.pitch_b = b.pitch;
+    g.pad_b = b.pad;
+    g.pitch = bias.pitch;
+    g.pad = bias.pad;
     g.ww = c.ww;
     g.wh = c.wh;
     g.wx0 = c.wx0;
@@ -520,8 +591,8 @@ hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, int32_t *b
     g.oy1 = c.oy1;
     g.ssd = c.ssd;
     g.shift = ilog2c(m.nd_per_thread);
-    g.bias = bias;
-    dim3 grid(ceil_div(b.pitch, 256), c.oy1 - c.oy0);
+    g.bias = reinterpret_cast<int32_t *>(bias.data);
+    dim3 grid(ceil_div(bias.pitch, 256), ceil_div(c.oy1 - c.oy0, kBiasRows));
     hipLaunchKernelGGL(ws_bias_kernel, grid, dim3(256), 0, s, g);
     return hipGetLastError();
 }
@@ -532,15 +603,17 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &)
     return e ? e->name : "";
 }
 
-hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b,
-                        const int32_t *bias, float *out, int out_pitch, hipStream_t s)
+hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
+                        float *out, int out_pitch, hipStream_t s)
 {
     const MarchEntry *e = find_march(c);
     if (!e) return hipErrorInvalidValue;
     MarchArgs g{};
     g.A = a.data;
     g.B = b.data;
-    g.bias = bias;
+    g.bias = reinterpret_cast<const int32_t *>(bias.data);
+    g.pitch_bi = bias.pitch;
+    g.pad_bi = bias.pad;
     g.out = out;
     g.pitch_a = a.pitch;
     g.pad_a = a.pad;
@@ -555,6 +628,9 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b,
     g.boff = c.boff;
     g.d_lo = c.d_lo;
     g.d_hi = c.d_hi;
+    g.b_lo = c.b_lo;
+    g.b_hi = c.b_hi;
+    g.tag_bits = tag_bits_for(c);
     g.ox0 = c.ox0;
     g.ox1 = c.ox1;
     g.oy0 = c.oy0;
@@ -594,13 +670,37 @@ __device__ __forceinline__ uint32_t window_cost(const uint8_t *a, int sa, const 
 
 __device__ __forceinline__ bool black3(const uint8_t *p) { return (p[0] | p[1] | p[2]) == 0; }
 
+// The pixels outside the skip rectangle, enumerated densely: rows above it, rows below it, then
+// for the rows beside it the columns left and right of it.
+__device__ __forceinline__ bool ring_pixel(const GenericArgs &g, int ow, int oh, long long idx, int *px, int *py)
+{
+    const long long n_top = (long long)g.skip_y0 * ow;
+    const long long n_bot = (long long)(oh - g.skip_y1) * ow;
+    const int side = g.skip_x0 + (ow - g.skip_x1);
+    const long long n_side = (long long)(g.skip_y1 - g.skip_y0) * side;
+    if (idx < n_top) {
+        *py = (int)(idx / ow);
+        *px = (int)(idx % ow);
+    } else if (idx < n_top + n_bot) {
+        idx -= n_top;
+        *py = g.skip_y1 + (int)(idx / ow);
+        *px = (int)(idx % ow);
+    } else if (idx < n_top + n_bot + n_side) {
+        idx -= n_top + n_bot;
+        *py = g.skip_y0 + (int)(idx / side);
+        const int k = (int)(idx % side);
+        *px = k < g.skip_x0 ? k : g.skip_x1 + (k - g.skip_x0);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
     const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
-    if (x >= ow || y >= oh) return;
-    if (x >= g.skip_x0 && x < g.skip_x1 && y >= g.skip_y0 && y < g.skip_y1) return;
+    int x, y;
+    if (!ring_pixel(g, ow, oh, (long long)blockIdx.x * blockDim.x + threadIdx.x, &x, &y)) return;
     const int height = min(g.h1, g.h2);
     float val = 0.0f;
     if (g.view == 0) { // BlockSearch.cpp:24-86
@@ -665,7 +765,10 @@ __global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s)
 {
     const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
-    dim3 grid(ceil_div(ow, 256), oh);
+    const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
+    const long long n = (long long)ow * oh - (inside > 0 ? inside : 0);
+    if (n <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL(ws_generic_kernel, grid, dim3(256), 0, s, g);
     return hipGetLastError();
 }
