@@ -195,8 +195,8 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         pbi.data = static_cast<uint32_t *>(ctx->bias.p);
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
-        WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, c.mirror, pa, s));
-        WS_HIP(ctx, launch_pack(ib->data, ib->width, ib->height, ib->stride, c.mirror, pb, s));
+        WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, pa, ib->data, ib->width,
+                                ib->height, ib->stride, pb, c.mirror, s));
         if (c.ssd) WS_HIP(ctx, launch_bias(c, m, pb, pbi, s));
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, s));

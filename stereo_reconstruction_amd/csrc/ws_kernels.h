@@ -54,7 +54,8 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
 // Plane geometry (pad / pitch) the plan needs.
 void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias);
 
-hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror, Plane dst,
+hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
+                       const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
                        hipStream_t s);
 hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s);
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,

@@ -61,18 +61,25 @@ __device__ __forceinline__ uint32_t pix_dot(uint32_t a, uint32_t b, uint32_t acc
 // ------------------------------------------------------------------------------------------
 // pack: CV_8UC3 rows -> padded dword plane
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ws_pack_kernel(const uint8_t *__restrict__ src, int w, int h,
-                                                      int stride, int mirror,
-                                                      uint32_t *__restrict__ dst, int pitch, int pad)
+struct PackArgs { // blockIdx.z selects the image: both planes are packed by one launch
+    const uint8_t *src[2];
+    uint32_t *dst[2];
+    int w[2], h[2], stride[2], pitch[2], pad[2];
+    int mirror;
+};
+
+__global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
 {
     // one thread = 4 consecutive plane columns (one 16-byte store); pitch is a multiple of 4
+    const int z = blockIdx.z;
+    const int w = g.w[z], h = g.h[z], pitch = g.pitch[z];
     const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y;
     if (col >= pitch || y >= h) return;
-    const int x = col - pad;
-    const uint8_t *row = src + (size_t)y * stride;
+    const int x = col - g.pad[z];
+    const uint8_t *row = g.src[z] + (size_t)y * g.stride[z];
     uint32_t v[4] = {0u, 0u, 0u, 0u};
-    if (!mirror && x >= 0 && x + 3 < w && ((reinterpret_cast<uintptr_t>(row) + 3 * (size_t)x) & 3) == 0) {
+    if (!g.mirror && x >= 0 && x + 3 < w && ((reinterpret_cast<uintptr_t>(row) + 3 * (size_t)x) & 3) == 0) {
         // 12 bytes = 3 aligned dwords = 4 BGR pixels
         const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * (size_t)x);
         const uint32_t a = p[0], b = p[1], c = p[2];
@@ -85,21 +92,27 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const uint8_t *__restrict_
         for (int k = 0; k < 4; ++k) {
             int xs = x + k;
             if (xs >= 0 && xs < w) {
-                if (mirror) xs = w - 1 - xs;
+                if (g.mirror) xs = w - 1 - xs;
                 const uint8_t *p = row + (size_t)xs * 3;
                 v[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
             }
         }
     }
-    *reinterpret_cast<uint4 *>(dst + (size_t)y * pitch + col) = make_uint4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<uint4 *>(g.dst[z] + (size_t)y * pitch + col) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-hipError_t launch_pack(const uint8_t *src, int w, int h, int stride, int mirror, Plane dst,
+hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
+                       const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
                        hipStream_t s)
 {
-    dim3 grid(ceil_div(dst.pitch / 4, 256), h);
-    hipLaunchKernelGGL(ws_pack_kernel, grid, dim3(256), 0, s, src, w, h, stride, mirror, dst.data,
-                       dst.pitch, dst.pad);
+    PackArgs g{};
+    g.src[0] = src_a; g.dst[0] = dst_a.data; g.w[0] = wa; g.h[0] = ha; g.stride[0] = stride_a;
+    g.pitch[0] = dst_a.pitch; g.pad[0] = dst_a.pad;
+    g.src[1] = src_b; g.dst[1] = dst_b.data; g.w[1] = wb; g.h[1] = hb; g.stride[1] = stride_b;
+    g.pitch[1] = dst_b.pitch; g.pad[1] = dst_b.pad;
+    g.mirror = mirror;
+    dim3 grid(ceil_div(std::max(dst_a.pitch, dst_b.pitch) / 4, 256), std::max(ha, hb), 2);
+    hipLaunchKernelGGL(ws_pack_kernel, grid, dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
@@ -116,7 +129,8 @@ struct BiasArgs {
     int32_t *bias;
 };
 
-constexpr int kBiasRows = 8;  // rows per thread: the vertical box sum slides down this many rows
+constexpr int kBiasRows = 32;  // output rows per workgroup
+constexpr int kBiasMaxWh = 16; // tallest window with a marching instantiation
 
 __device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww)
 {
@@ -125,29 +139,41 @@ __device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww)
     return acc;
 }
 
+// Separable box filter of the squared target pixels: a workgroup (64 x 4 threads) owns 64 columns
+// x kBiasRows rows.  Thread (tx, ty) fills every 4th horizontal sum of column tx in LDS, then
+// slides the vertical sum down its quarter of the strip.
 __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t hs[kBiasRows + kBiasMaxWh - 1][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * 64 + tx;
     const int y0 = g.oy0 + blockIdx.y * kBiasRows;
     const int y1 = min(y0 + kBiasRows, g.oy1);
-    if (col >= g.pitch || y0 >= y1) return;
     const int xb = col - g.pad;
-    int32_t *dst = g.bias + (size_t)y0 * g.pitch + col;
-    if (xb < g.b_lo || xb > g.b_hi || !g.ssd) {
-        const int32_t v = (xb < g.b_lo || xb > g.b_hi) ? kPoison : 0;
-        for (int y = y0; y < y1; ++y, dst += g.pitch) *dst = v;
+    const bool in_plane = col < g.pitch;
+    const bool centre_ok = in_plane && xb >= g.b_lo && xb <= g.b_hi;
+    if (centre_ok && g.ssd) {
+        const int nrows = (y1 - y0) + g.wh - 1;
+        const uint32_t *src = g.B + (size_t)(y0 + g.wy0) * g.pitch_b + (xb + g.pad_b + g.wx0);
+        for (int k = ty; k < nrows; k += 4) hs[k][tx] = row_square_sum(src + (size_t)k * g.pitch_b, g.ww);
+    }
+    __syncthreads();
+    if (!in_plane) return;
+    const int seg = kBiasRows / 4;
+    const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
+    if (ya >= yb) return;
+    int32_t *dst = g.bias + (size_t)ya * g.pitch + col;
+    if (!centre_ok || !g.ssd) {
+        const int32_t v = centre_ok ? 0 : kPoison;
+        for (int y = ya; y < yb; ++y, dst += g.pitch) *dst = v;
         return;
     }
-    // box sum of squared target pixels: horizontal sums per row, vertical sum slid down the strip
-    const uint32_t *top = g.B + (size_t)(y0 + g.wy0) * g.pitch_b + (xb + g.pad_b + g.wx0);
     uint32_t acc = 0;
-    for (int wy = 0; wy < g.wh; ++wy) acc += row_square_sum(top + (size_t)wy * g.pitch_b, g.ww);
-    for (int y = y0; y < y1; ++y, dst += g.pitch) {
+    for (int k = 0; k < g.wh; ++k) acc += hs[ya - y0 + k][tx];
+    for (int y = ya; y < yb; ++y, dst += g.pitch) {
         *dst = (int32_t)(acc << g.shift);
-        if (y + 1 < y1) {
-            acc += row_square_sum(top + (size_t)g.wh * g.pitch_b, g.ww) - row_square_sum(top, g.ww);
-            top += g.pitch_b;
-        }
+        const int k = y - y0;
+        if (y + 1 < yb) acc += hs[k + g.wh][tx] - hs[k][tx];
     }
 }
 
@@ -592,8 +618,8 @@ hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias
     g.ssd = c.ssd;
     g.shift = ilog2c(m.nd_per_thread);
     g.bias = reinterpret_cast<int32_t *>(bias.data);
-    dim3 grid(ceil_div(bias.pitch, 256), ceil_div(c.oy1 - c.oy0, kBiasRows));
-    hipLaunchKernelGGL(ws_bias_kernel, grid, dim3(256), 0, s, g);
+    dim3 grid(ceil_div(bias.pitch, 64), ceil_div(c.oy1 - c.oy0, kBiasRows));
+    hipLaunchKernelGGL(ws_bias_kernel, grid, dim3(64, 4), 0, s, g);
     return hipGetLastError();
 }
 
