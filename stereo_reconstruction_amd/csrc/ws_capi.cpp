@@ -196,7 +196,7 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
         WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, pa, ib->data, ib->width,
-                                ib->height, ib->stride, pb, c.mirror, s));
+                                ib->height, ib->stride, pb, c.mirror, march_centred(c), s));
         if (c.ssd) WS_HIP(ctx, launch_bias(c, m, pb, pbi, s));
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, s));

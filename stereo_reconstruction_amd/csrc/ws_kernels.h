@@ -48,6 +48,8 @@ struct MarchLaunch {
 
 // Which (window, X, ND) instantiations exist.  Returns false if none fits.
 bool march_supported(const Canon &c);
+// 1 if this SSD window needs centred (byte - 128) planes to keep its sums in 32 bits
+int march_centred(const Canon &c);
 // Fill the tiling for this problem (tuning values of 0 = automatic).
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out);
@@ -56,7 +58,7 @@ void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane 
 
 hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
                        const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
-                       hipStream_t s);
+                       int centred, hipStream_t s);
 hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s);
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
                         float *out, int out_pitch, hipStream_t s);

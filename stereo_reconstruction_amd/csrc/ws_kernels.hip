@@ -53,9 +53,24 @@ __device__ __forceinline__ uint32_t pix_sad(uint32_t a, uint32_t b, uint32_t acc
 {
     return __builtin_amdgcn_sad_u8(a, b, acc); // v_sad_u8: acc + sum |a.b[i] - b.b[i]|
 }
+// SSD cross products.  Windows up to 9x9 use the bytes as they are (v_dot4_u32_u8).  Larger
+// windows would overflow the 32-bit keys, so their planes hold centred pixels (byte - 128, i.e.
+// byte ^ 0x80, 4th byte 0) multiplied by v_dot4_i32_i8: the differences and hence the SSD are
+// unchanged, the products are 4x smaller.  (The signed form measured 18 % slower on MI355X, so it
+// is only used where it is needed.)
+template <bool CENTRED>
 __device__ __forceinline__ uint32_t pix_dot(uint32_t a, uint32_t b, uint32_t acc)
 {
-    return __builtin_amdgcn_udot4(a, b, acc, false); // v_dot4_u32_u8: acc + sum a.b[i] * b.b[i]
+    if constexpr (CENTRED)
+        return (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); // v_dot4_i32_i8
+    else
+        return __builtin_amdgcn_udot4(a, b, acc, false); // v_dot4_u32_u8
+}
+constexpr uint32_t kCentre = 0x00808080u;
+// does an SSD window of ww x wh need centred pixels to keep |key| < 2^28 with nd tags per thread?
+__host__ __device__ constexpr bool ssd_needs_centring(int ww, int wh, int nd)
+{
+    return 2LL * ww * wh * 3 * 255 * 255 * nd >= (1LL << 28);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -66,6 +81,7 @@ struct PackArgs { // blockIdx.z selects the image: both planes are packed by one
     uint32_t *dst[2];
     int w[2], h[2], stride[2], pitch[2], pad[2];
     int mirror;
+    uint32_t xor_mask; // kCentre for SSD planes, 0 for SAD
 };
 
 __global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
@@ -83,10 +99,10 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
         // 12 bytes = 3 aligned dwords = 4 BGR pixels
         const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * (size_t)x);
         const uint32_t a = p[0], b = p[1], c = p[2];
-        v[0] = a & 0xffffffu;
-        v[1] = (a >> 24) | ((b & 0xffffu) << 8);
-        v[2] = (b >> 16) | ((c & 0xffu) << 16);
-        v[3] = c >> 8;
+        v[0] = (a & 0xffffffu) ^ g.xor_mask;
+        v[1] = ((a >> 24) | ((b & 0xffffu) << 8)) ^ g.xor_mask;
+        v[2] = ((b >> 16) | ((c & 0xffu) << 16)) ^ g.xor_mask;
+        v[3] = (c >> 8) ^ g.xor_mask;
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -94,7 +110,7 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
             if (xs >= 0 && xs < w) {
                 if (g.mirror) xs = w - 1 - xs;
                 const uint8_t *p = row + (size_t)xs * 3;
-                v[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+                v[k] = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) ^ g.xor_mask;
             }
         }
     }
@@ -103,9 +119,10 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
 
 hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
                        const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
-                       hipStream_t s)
+                       int centred, hipStream_t s)
 {
     PackArgs g{};
+    g.xor_mask = centred ? kCentre : 0u;
     g.src[0] = src_a; g.dst[0] = dst_a.data; g.w[0] = wa; g.h[0] = ha; g.stride[0] = stride_a;
     g.pitch[0] = dst_a.pitch; g.pad[0] = dst_a.pad;
     g.src[1] = src_b; g.dst[1] = dst_b.data; g.w[1] = wb; g.h[1] = hb; g.stride[1] = stride_b;
@@ -125,17 +142,20 @@ struct BiasArgs {
     int pitch, pad;     // the bias plane (own padding: its row copies must start 16-byte aligned)
     int ww, wh, wx0, wy0;
     int b_lo, b_hi, oy0, oy1;
-    int ssd, shift;
+    int ssd, shift, centred;
     int32_t *bias;
 };
 
 constexpr int kBiasRows = 32;  // output rows per workgroup
-constexpr int kBiasMaxWh = 16; // tallest window with a marching instantiation
+constexpr int kBiasMaxWh = 17; // tallest window with a marching instantiation
 
-__device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww)
+__device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww, int centred)
 {
     uint32_t acc = 0;
-    for (int wx = 0; wx < ww; ++wx) acc = pix_dot(row[wx], row[wx], acc);
+    if (centred)
+        for (int wx = 0; wx < ww; ++wx) acc = pix_dot<true>(row[wx], row[wx], acc);
+    else
+        for (int wx = 0; wx < ww; ++wx) acc = pix_dot<false>(row[wx], row[wx], acc);
     return acc;
 }
 
@@ -155,7 +175,7 @@ __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
     if (centre_ok && g.ssd) {
         const int nrows = (y1 - y0) + g.wh - 1;
         const uint32_t *src = g.B + (size_t)(y0 + g.wy0) * g.pitch_b + (xb + g.pad_b + g.wx0);
-        for (int k = ty; k < nrows; k += 4) hs[k][tx] = row_square_sum(src + (size_t)k * g.pitch_b, g.ww);
+        for (int k = ty; k < nrows; k += 4) hs[k][tx] = row_square_sum(src + (size_t)k * g.pitch_b, g.ww, g.centred);
     }
     __syncthreads();
     if (!in_plane) return;
@@ -254,7 +274,7 @@ __device__ __forceinline__ void stage_row_async(uint32_t *row, int ro, const uin
 //        (bias = box sum of the squared target pixels << LT, or poison for an invalid centre)
 // With KEY the candidate keys are folded into best[] (signed min; equal costs go to the smaller
 // tag, i.e. to the disparity the reference's strict '<' keeps).
-template <int X, int ND, int WW, bool SSD, int SIGN, bool KEY>
+template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
 __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X],
                                           const uint32_t *runA, int ro_a, const uint32_t *runB,
                                           int ro_b, const int32_t *runBias, int ro_bi, int shift)
@@ -281,8 +301,8 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const uint32_t b0 = pb[i - j + ND - 1], b1 = pb[i - j + ND - 2];
-            s0 = SSD ? pix_dot(pa[i], b0, s0) : pix_sad(pa[i], b0, s0);
-            s1 = SSD ? pix_dot(pa[i], b1, s1) : pix_sad(pa[i], b1, s1);
+            s0 = SSD ? pix_dot<CENTRED>(pa[i], b0, s0) : pix_sad(pa[i], b0, s0);
+            s1 = SSD ? pix_dot<CENTRED>(pa[i], b1, s1) : pix_sad(pa[i], b1, s1);
             S0[i] = s0;
             S1[i] = s1;
         }
@@ -307,6 +327,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     static_assert(X % 4 == 0 && ND % X == 0 && ND % 2 == 0, "run starts must stay region aligned");
     constexpr int NREG = X / 4;
     constexpr int LT = ilog2c(ND);
+    constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
     constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
     typedef typename std::conditional<SSD, unsigned long long, int32_t>::type slot_t;
     const slot_t kEmpty = SSD ? (slot_t)~0ull : (slot_t)INT_MAX;
@@ -405,7 +426,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                         val = (float)(g.prefer_large ? g.d_hi - gtag : g.d_lo + gtag);
                     }
                     // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
-                    if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == 0u) val = 0.0f;
+                    if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
                     g.out[(size_t)y * g.out_pitch + xo] = val;
                 }
             }
@@ -429,10 +450,10 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 #pragma unroll
             for (int x = 0; x < X; ++x) best[x] = INT_MAX;
             if (a >= WH)
-                march_row<X, ND, WW, SSD, -1, false>(V, best, ringA + sub_slot * a_w + ia, ro_a,
+                march_row<X, ND, WW, SSD, CENTRED, -1, false>(V, best, ringA + sub_slot * a_w + ia, ro_a,
                                                      ringB + sub_slot * b_w + ib, ro_b, nullptr, 0, shift);
             if (oi >= 0) {
-                march_row<X, ND, WW, SSD, +1, true>(V, best, ringA + add_slot * a_w + ia, ro_a,
+                march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, ringA + add_slot * a_w + ia, ro_a,
                                                     ringB + add_slot * b_w + ib, ro_b,
                                                     biasr + (oi & 1) * bi_w + ib, ro_bi, shift);
                 slot_t *sl = slots + (oi & 1) * tx + r;
@@ -452,7 +473,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     }
                 }
             } else {
-                march_row<X, ND, WW, SSD, +1, false>(V, best, ringA + add_slot * a_w + ia, ro_a,
+                march_row<X, ND, WW, SSD, CENTRED, +1, false>(V, best, ringA + add_slot * a_w + ia, ro_a,
                                                      ringB + add_slot * b_w + ib, ro_b, nullptr, 0, shift);
             }
         }
@@ -487,8 +508,11 @@ struct MarchEntry {
     {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, "ws_march_kernel<sad," #W "x" #H ">"}, \
     {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, "ws_march_kernel<ssd," #W "x" #H ">"}
 static const MarchEntry kMarchTable[] = {
+    // left view: bs x bs                       right view: (bs-1) x (bs-1)
     WS_MARCH_ENTRY(3, 3), WS_MARCH_ENTRY(5, 5), WS_MARCH_ENTRY(7, 7), WS_MARCH_ENTRY(9, 9),
+    WS_MARCH_ENTRY(11, 11), WS_MARCH_ENTRY(13, 13), WS_MARCH_ENTRY(15, 15), WS_MARCH_ENTRY(17, 17),
     WS_MARCH_ENTRY(2, 2), WS_MARCH_ENTRY(4, 4), WS_MARCH_ENTRY(6, 6), WS_MARCH_ENTRY(8, 8),
+    WS_MARCH_ENTRY(10, 10), WS_MARCH_ENTRY(12, 12), WS_MARCH_ENTRY(14, 14), WS_MARCH_ENTRY(16, 16),
 };
 
 static const MarchEntry *find_march(const Canon &c)
@@ -505,6 +529,8 @@ static int tag_bits_for(const Canon &c)
     return bits;
 }
 
+int march_centred(const Canon &c) { return c.ssd && ssd_needs_centring(c.ww, c.wh, kND); }
+
 bool march_supported(const Canon &c)
 {
     if (!find_march(c)) return false;
@@ -514,7 +540,7 @@ bool march_supported(const Canon &c)
     if (ceil_div(dcount, kND) > kMaxT / kMinXRuns) return false;
     // keys must stay inside (-2^28, 2^28)
     //   SSD: (2 * cross sum) << log2(ND)        SAD: window sum << tag bits
-    const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * 255 * 255 * kND
+    const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * (march_centred(c) ? 128 * 128 : 255 * 255) * kND
                                   : ((long long)c.ww * c.wh * 3 * 255) << tag_bits_for(c);
     return worst < (long long)kValidKeyBound;
 }
@@ -617,6 +643,7 @@ hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias
     g.oy1 = c.oy1;
     g.ssd = c.ssd;
     g.shift = ilog2c(m.nd_per_thread);
+    g.centred = march_centred(c);
     g.bias = reinterpret_cast<int32_t *>(bias.data);
     dim3 grid(ceil_div(bias.pitch, 64), ceil_div(c.oy1 - c.oy0, kBiasRows));
     hipLaunchKernelGGL(ws_bias_kernel, grid, dim3(64, 4), 0, s, g);

@@ -44,7 +44,7 @@ def test_golden_fixtures(wslib, gpu_ctx, name):
 
 @pytest.mark.parametrize("view", ["left", "right"])
 @pytest.mark.parametrize("cost", ["ssd", "sad"])
-@pytest.mark.parametrize("bs", [3, 5, 7, 9])
+@pytest.mark.parametrize("bs", [3, 5, 7, 9, 11, 13, 15, 17])
 def test_marching_kernel_matches_oracle(wslib, gpu_ctx, oracle, view, cost, bs):
     left, right, _ = make_pair(331, 75, 70, seed=10 * bs + (view == "left"))
     left[30, 100] = 0
@@ -102,7 +102,7 @@ def test_tiny_and_ragged_images(wslib, gpu_ctx, oracle):
             assert np.array_equal(got, ref(oracle, view, left, right, 3, 0, 8, "sad")), (h, w, view)
 
 
-@pytest.mark.parametrize("bs,view", [(1, "left"), (11, "left"), (17, "right"), (2, "right"), (21, "left")])
+@pytest.mark.parametrize("bs,view", [(1, "left"), (19, "left"), (23, "right"), (2, "right"), (21, "left")])
 def test_window_sizes_on_the_brute_force_kernel(wslib, gpu_ctx, oracle, bs, view):
     left, right, _ = make_pair(120, 48, 24, seed=bs)
     got = run(wslib, gpu_ctx, view, left, right, bs, 0, 24, "ssd")

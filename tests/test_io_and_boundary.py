@@ -68,6 +68,7 @@ def test_plan_covers_the_baseline_configs(wslib):
         assert p["marching"] == 1, (w, h, d)
         assert p["d_chunks"] * p["d_per_thread"] >= d
         assert p["threads"] % 64 == 0 and p["threads"] <= 1024
+        assert p["x_runs"] >= 4
         assert p["threads"] >= p["x_runs"] * p["d_chunks"]
         assert p["tiles"] * p["x_runs"] * p["x_per_thread"] >= w - 2 * half
         assert p["strips"] * p["strip_rows"] >= h - 2 * half

@@ -33,8 +33,13 @@ cases = [
     ("right", 7, 2, 50, "sad", (300, 80), (310, 78), 256),
     ("right", 9, 0, 90, "ssd", (333, 64), None, 4),
     ("right", 5, 0, 33, "sad", (200, 50), None, 2),
-    ("left", 11, 0, 30, "ssd", (120, 50), None, 256),   # generic path
-    ("right", 17, 0, 40, "ssd", (150, 60), None, 256),  # generic path
+    ("left", 11, 0, 30, "ssd", (120, 50), None, 256),
+    ("right", 17, 0, 40, "ssd", (150, 60), None, 256),
+    ("right", 17, 0, 200, "ssd", (450, 90), None, 256),
+    ("left", 17, 0, 100, "ssd", (300, 70), None, 4),
+    ("left", 15, 0, 64, "sad", (300, 70), None, 2),
+    ("right", 13, 3, 64, "sad", (300, 70), (280, 66), 256),
+    ("left", 21, 0, 30, "ssd", (120, 50), None, 256),   # generic path
     ("left", 1, 0, 20, "ssd", (90, 30), None, 256),
 ]
 for view, bs, mind, maxd, cost, (w, h), wh2, levels in cases:

@@ -1,0 +1,58 @@
+"""LDS tile-size sweep of the marching kernel (BASELINE.json config 3: 9x9 SAD, D=512, 2964x1988).
+
+Sweeps x-runs per tile (tile width = 8 * x_runs columns; the tile always holds all D disparities)
+and strip height through ws_set_tuning, times the marching kernel alone with HIP events, checks a
+row band against the oracle once, and writes a CSV.  Run on the GPU box:
+    python tools/sweep_tiles.py config3 gpurun_out/sweep_config3.csv
+"""
+import csv, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import stereo_reconstruction_amd as ws
+from stereo_reconstruction_amd.synthetic import make_pair
+from bench import WORKLOADS
+
+name = sys.argv[1] if len(sys.argv) > 1 else "config3"
+out_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/sweep_%s.csv" % name
+w, h, bs, cost, maxd, seed = WORKLOADS[name]
+left, right, _ = make_pair(w, h, maxd, seed)
+tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+out = torch.empty((h, w), dtype=torch.float32, device="cuda")
+ctx = ws.WindowSearch(0)
+p = ws.make_params(ws.VIEW_LEFT, bs, 0, maxd, 1.0, cost)
+stream = torch.cuda.current_stream().cuda_stream
+base = ws.plan(p, (h, w), (h, w))
+nch = base["d_chunks"]
+ref = None
+rows = []
+alg_bytes = 10.0 * w * h
+for nxr in sorted({4, 6, 8, 12, 16, 24, 32, 48, 64} | {base["x_runs"]}):
+    if nxr * nch > 512:
+        continue
+    for strip in (8, 16, 32, 64, 128, 256, 0):
+        ctx.set_tuning(nxr, strip, 0)
+        ctx.set_profiling(True)
+        ts = []
+        for i in range(6):
+            ctx.search_device(p, tl, tr, out, stream)
+            ts.append(ctx.last_kernel_ms())
+        ctx.set_profiling(False)
+        info = ctx.last_launch()
+        ms = float(np.median(ts[1:]))
+        got = out[h // 2:h // 2 + 2].cpu().numpy().astype(np.float64)
+        if ref is None:
+            from oracle import oracle
+            ref = oracle.block_left(left, right, bs, 0, maxd, cost=cost, rows=(h // 2, h // 2 + 2), threads=16)[h // 2:h // 2 + 2]
+        ok = bool(np.array_equal(got, ref))
+        rows.append({"workload": name, "x_runs": nxr, "tile_cols": 8 * nxr, "strip_rows": strip or "auto",
+                     "threads": info["threads"], "workgroups": info["workgroups"], "lds_bytes": info["lds_bytes"],
+                     "kernel_ms": round(ms, 4), "Mdisp_per_s": round(w * h * maxd / ms / 1e3, 0),
+                     "alg_GBps": round(alg_bytes / ms / 1e6, 1), "bit_exact_band": ok})
+        print(rows[-1], flush=True)
+with open(out_path, "w", newline="") as f:
+    wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    wr.writeheader()
+    wr.writerows(rows)
+best = min(rows, key=lambda r: r["kernel_ms"])
+print("BEST", best)
