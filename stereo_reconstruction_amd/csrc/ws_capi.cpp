@@ -45,7 +45,7 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, sel, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
@@ -100,13 +100,15 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
     if (p->view != WS_VIEW_LINEAR && (p->block_size < 1 || p->block_size > 63))
         return fail(ctx, WS_ERR_ARG, "blockSize %d outside [1,63]", p->block_size);
     if (p->view == WS_VIEW_LINEAR && p->linear_range < 1) return fail(ctx, WS_ERR_ARG, "linear_range < 1");
-    if (p->smooth_factor != 1.0)
+    if (p->smooth_factor != 1.0 && p->view == WS_VIEW_LEFT)
         return fail(ctx, WS_ERR_UNSUPPORTED,
-                    "smoothFactor %.3f: only 1.0 runs on the device (raster-order dependency, BlockSearch.cpp:68-73)",
-                    p->smooth_factor);
+                    "smoothFactor %.3f in the left view: only 1.0 runs on the device (true raster-order dependency, "
+                    "BlockSearch.cpp:68-73)", p->smooth_factor);
+    if (!(p->smooth_factor == p->smooth_factor)) return fail(ctx, WS_ERR_ARG, "smoothFactor is NaN");
     if (p->var_block && p->view == WS_VIEW_RIGHT)
         return fail(ctx, WS_ERR_UNSUPPORTED, "varBlock is not implemented on the device (BlockSearch.cpp:129-142)");
     if (p->subpixel && p->view == WS_VIEW_LINEAR) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel on LinearSearch");
+    if (p->subpixel && p->smooth_factor != 1.0) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
     const int h1 = L->height, w1 = L->width, h2 = R->height, w2 = R->width;
     const int height = std::min(h1, h2);
     const int half = (p->block_size - 1) / 2;
@@ -164,7 +166,38 @@ bool make_canon(const ws_params *p, const ws_image *L, const ws_image *R, Canon 
     return k.ox1 > k.ox0 && k.oy1 > k.oy0 && k.d_hi >= k.d_lo;
 }
 
+int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
+               float *out, int out_stride, hipStream_t s);
+
+// smoothFactor: for the right view and LinearSearch the factor can only reach d = 0 beside a
+// zero-valued neighbour (see ws_kernels.hip), and only when d = 0 is a candidate at all.
 int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
+               float *out, int out_stride, hipStream_t s)
+{
+    ws_params q = *p;
+    if (q.view == WS_VIEW_LINEAR) q.min_disparity = 0;
+    const bool smooth = q.smooth_factor != 1.0 && q.view != WS_VIEW_LEFT && q.min_disparity == 0;
+    if (!smooth) return run_search(ctx, &q, L, R, out, out_stride, s);
+    q.min_disparity = 1; // the data-parallel part: best candidate among d >= 1
+    q.subpixel = 0;
+    int rc = run_search(ctx, &q, L, R, out, out_stride, s);
+    if (rc != WS_OK) return rc;
+    const int sel_pitch = (R->width + 63) & ~63;
+    if ((rc = ensure(ctx, ctx->sel, (size_t)sel_pitch * R->height)) != WS_OK) return rc;
+    GenericArgs ga{};
+    ga.L = L->data; ga.R = R->data;
+    ga.w1 = L->width; ga.h1 = L->height; ga.s1 = L->stride;
+    ga.w2 = R->width; ga.h2 = R->height; ga.s2 = R->stride;
+    ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
+    ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
+    ga.linear_range = p->linear_range;
+    ga.out = out; ga.out_pitch = out_stride;
+    WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch, s));
+    if (p->subpixel) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
+    return WS_OK;
+}
+
+int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
                float *out, int out_stride, hipStream_t s)
 {
     const int ow = p->view == WS_VIEW_LEFT ? L->width : R->width;
@@ -294,7 +327,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->sel, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);

@@ -78,6 +78,8 @@ struct GenericArgs {
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
 // Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
+// smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
+hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st);
 // float32 -> float64 widening for CV_64F outputs
 hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
                         hipStream_t s);

@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
             const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
             uint32_t best = 0xffffffffu;
             int col = 0;
-            for (int k = x; k < x + g.linear_range; ++k) {
+            for (int k = x + g.min_d; k < x + g.linear_range; ++k) {
                 if (k >= g.w1) break;
                 const uint32_t cst = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * k, 0, 1, 1, 1);
                 if (cst < best) {
@@ -882,6 +882,175 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s)
     const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
     dim3 grid(ceil_div(ow, 256), oh);
     hipLaunchKernelGGL(ws_refine_kernel, grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// smoothFactor != 1 for the right view and LinearSearch
+//
+// There the reference compares a neighbour's stored value (>= 0, or the negative fallback) with
+// x - cx = -d (BlockSearch.cpp:160-165, LinearSearch.cpp:39-44), so the factor can only ever hit
+// d = 0 next to a neighbour whose stored value is 0 (the fallback cases cannot coincide with a
+// pixel that still has candidates).  Since d = 0 is tried first, the pixel's value is
+//     0            if  !(c1 < c0 * s^k)      k = [up == 0] + [left == 0]
+//     argmin_{d>=1}  otherwise
+// with c0 / c1 the reference's doubles (sqrt, / area, successive multiplications).  The search for
+// d >= 1 is the ordinary data-parallel search; what is left is a boolean recurrence in raster
+// order, solved row by row with a scan over function composition.
+// ------------------------------------------------------------------------------------------
+constexpr uint8_t kSelFixed = 0x80; // value in the map is final; otherwise bits 0..2 = t_0..t_2
+
+__global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArgs g, double s,
+                                                                uint8_t *__restrict__ sel, int sel_pitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= g.w2 || y >= g.h2) return;
+    float *o = g.out + (size_t)y * g.out_pitch + x;
+    uint8_t code = kSelFixed;
+    float val = 0.0f;
+    const int height = min(g.h1, g.h2);
+    if (g.view == 1) {
+        if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+            const int half = (g.block_size - 1) / 2;
+            const int left = min(x, half), right = min(g.w2 - x - 1, half);
+            const int up = min(y, half), down = min(g.h2 - y - 1, half);
+            const int ww = left + right, wh = up + down;
+            const bool any = ww > 0 && wh > 0 && g.max_d > 0 && x + right < g.w1;
+            if (!any) {
+                val = -(float)x; // no candidate at all: stores -x (BlockSearch.cpp:174)
+            } else if (!(g.max_d > 1 && x + 1 + right < g.w1)) {
+                val = 0.0f; // d = 0 is the only candidate
+            } else {
+                const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                const int d1 = (int)*o;
+                const uint32_t c0 = window_cost(g.L + (size_t)(y - up) * g.s1 + 3 * (x - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const uint32_t c1 = window_cost(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const double area = (double)(ww * wh);
+                const double e1 = (g.ssd ? sqrt((double)c1) : (double)c1) / area;
+                double e0 = (g.ssd ? sqrt((double)c0) : (double)c0) / area;
+                code = 0;
+                if (e1 < e0) code |= 1;
+                e0 *= s;
+                if (e1 < e0) code |= 2;
+                e0 *= s;
+                if (e1 < e0) code |= 4;
+                val = (float)d1;
+            }
+        }
+    } else { // LinearSearch: black test on the left pixel, distance of single pixels
+        if (y < g.h1 && !(x < g.w1 && black3(g.L + (size_t)y * g.s1 + 3 * x))) {
+            if (!(x < g.w1)) {
+                val = -(float)x;
+            } else if (!(g.linear_range > 1 && x + 1 < g.w1)) {
+                val = 0.0f;
+            } else {
+                const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
+                const int d1 = (int)*o;
+                const uint32_t c0 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * x, 0, 1, 1, 1);
+                const uint32_t c1 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * (x + d1), 0, 1, 1, 1);
+                const double e1 = sqrt((double)c1);
+                double e0 = sqrt((double)c0);
+                code = 0;
+                if (e1 < e0) code |= 1;
+                e0 *= s;
+                if (e1 < e0) code |= 2;
+                e0 *= s;
+                if (e1 < e0) code |= 4;
+                val = (float)d1;
+            }
+        }
+    }
+    *o = val;
+    sel[(size_t)y * sel_pitch + x] = code;
+}
+
+// compose two maps {0,1}->{0,1} stored as bit0 = f(0), bit1 = f(1):  (b o a)(v) = b(a(v))
+__device__ __forceinline__ uint32_t compose2(uint32_t a, uint32_t b)
+{
+    const uint32_t r0 = (b >> (a & 1)) & 1, r1 = (b >> ((a >> 1) & 1)) & 1;
+    return r0 | (r1 << 1);
+}
+
+// One workgroup walks the rows in order.  Per row every thread owns `per` consecutive columns,
+// composes their transition maps, the workgroup scans the compositions, and each thread replays
+// its columns with the incoming "left neighbour is 0" bit.
+__global__ void __launch_bounds__(1024) ws_smooth_resolve_kernel(float *out, int out_pitch, int w, int rows,
+                                                                 const uint8_t *__restrict__ sel, int sel_pitch)
+{
+    extern __shared__ uint8_t zrow[]; // zero flags of the previous row, then 16 words of wave totals
+    uint32_t *wave_tot = reinterpret_cast<uint32_t *>(zrow + ((w + 3) & ~3));
+    const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (w + nt - 1) / nt;
+    const int x0 = tid * per, x1 = min(x0 + per, w);
+    for (int x = tid; x < w; x += nt) zrow[x] = 0; // y = 0 has no upper neighbour
+    __syncthreads();
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *srow = sel + (size_t)y * sel_pitch;
+        float *orow = out + (size_t)y * out_pitch;
+        // 1. composition of this thread's columns
+        uint32_t f = 2; // identity: f(0)=0, f(1)=1
+        for (int x = x0; x < x1; ++x) {
+            const uint32_t c = srow[x];
+            uint32_t gmap;
+            if (c & kSelFixed) {
+                const uint32_t z = orow[x] == 0.0f;
+                gmap = z | (z << 1);
+            } else {
+                const uint32_t zu = zrow[x];
+                gmap = (((c >> zu) & 1) ^ 1) | ((((c >> (zu + 1)) & 1) ^ 1) << 1);
+            }
+            f = compose2(f, gmap);
+        }
+        // 2. exclusive scan of the compositions over the workgroup
+        uint32_t incl = f;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t prev = __shfl_up(incl, off, 64);
+            if (lane >= off) incl = compose2(prev, incl);
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t before = 2; // maps of all earlier waves
+        for (int k = 0; k < wv; ++k) before = compose2(before, wave_tot[k]);
+        uint32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 2;
+        excl = compose2(before, excl);
+        uint32_t b = excl & 1; // column 0 has no left neighbour: start from 0
+        // 3. replay
+        for (int x = x0; x < x1; ++x) {
+            const uint32_t c = srow[x];
+            uint32_t z;
+            if (c & kSelFixed) {
+                z = orow[x] == 0.0f;
+            } else {
+                const uint32_t k = zrow[x] + b;
+                z = ((c >> k) & 1) ^ 1;
+                if (z) orow[x] = 0.0f;
+            }
+            b = z;
+        }
+        __syncthreads(); // everyone has read zrow / wave_tot of this row
+        b = excl & 1;
+        for (int x = x0; x < x1; ++x) { // store this row's flags for the next one
+            const uint32_t c = srow[x];
+            const uint32_t z = orow[x] == 0.0f;
+            (void)c;
+            zrow[x] = (uint8_t)z;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st)
+{
+    dim3 grid(ceil_div(g.w2, 256), g.h2);
+    hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int rows = g.view == 1 ? std::min(g.h1, g.h2) : std::min(g.h1, g.h2);
+    const size_t lds = (size_t)((g.w2 + 3) & ~3) + 16 * sizeof(uint32_t);
+    hipLaunchKernelGGL(ws_smooth_resolve_kernel, dim3(1), dim3(1024), lds, st, g.out, g.out_pitch, g.w2, rows, sel,
+                       sel_pitch);
     return hipGetLastError();
 }
 

@@ -128,6 +128,36 @@ def test_subpixel_within_tolerance(wslib, gpu_ctx, oracle, view, cost):
         np.abs(np.round(got) - np.round(want)).max() <= 1
 
 
+@pytest.mark.parametrize("smooth", [0.9, 0.5, 1.7, 0.0])
+@pytest.mark.parametrize("levels", [256, 3])
+def test_smooth_factor_right_view_and_linear(wslib, gpu_ctx, oracle, smooth, levels):
+    """smoothFactor != 1 (the pipeline default is 0.9, main.cpp:40): right view and LinearSearch
+    reproduce the reference's raster-order rule exactly (it only ever reaches d = 0)."""
+    if levels == 256:
+        left, right, _ = make_pair(420, 56, 48, seed=31)
+    else:
+        rng = np.random.default_rng(7)
+        left = (rng.integers(0, levels, size=(56, 420, 3)) * (255 // (levels - 1))).astype(np.uint8)
+        right = (rng.integers(0, levels, size=(56, 420, 3)) * (255 // (levels - 1))).astype(np.uint8)
+    left[10:14, 20:60] = 0
+    right[5:9, 30:90] = 0
+    for bs, mind, cost in ((17, 0, "ssd"), (7, 0, "sad"), (7, 2, "ssd")):
+        got = wslib.BlockSearch(left, right, bs, mind, 48, cost=cost, context=gpu_ctx).computeDisparityMapRight(smooth)
+        want = oracle.block_right(left, right, bs, mind, 48, smooth=smooth, cost=cost)
+        assert np.array_equal(got, want), (bs, mind, cost)
+    got = wslib.LinearSearch(left, right, context=gpu_ctx).computeDisparityMap(smooth)
+    assert np.array_equal(got, oracle.linear(left, right, smooth=smooth))
+
+
+def test_reference_pipeline_call_on_teddy_sized_pair(wslib, gpu_ctx, oracle):
+    """main.cpp:40: computeDisparityMapRight(17, 0, 200, 0.9) at Teddy-H size (900 x 750)."""
+    left, right, _ = make_pair(900, 750, 200, seed=13)
+    got = wslib.BlockSearch(left, right, 17, 0, 200, context=gpu_ctx).computeDisparityMapRight(0.9)
+    assert "march" in gpu_ctx.last_launch()["kernel"]
+    band = oracle.block_right(left, right, 17, 0, 200, smooth=0.9, rows=(0, 12), threads=8)
+    assert np.array_equal(got[:12], band[:12])       # raster dependency: the oracle must start at row 0
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
