@@ -37,6 +37,8 @@ WORKLOADS = {
     "config5": (3840, 2160, 9, "ssd", 1024, 5),
     "config1": (450, 375, 5, "sad", 64, 1),
 }
+# BASELINE.json configs[3]: the 15 trainingH shapes, 7x7 SSD, D=256, sharded over the ranks
+# (strong scaling: the batch is fixed).  `--workload config4`.
 
 
 def host_cores():
@@ -56,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="compare a row band with the oracle")
@@ -82,18 +84,36 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
-    left, right, _gt = make_pair(width, height, max_d, seed + rank)
     dev = torch.device("cuda", local_rank)
-    t_left = torch.from_numpy(left).to(dev)
-    t_right = torch.from_numpy(right).to(dev)
-    t_out = torch.empty((height, width), dtype=torch.float32, device=dev)
     ctx = ws.WindowSearch(local_rank)
-    params = ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
     stream = torch.cuda.current_stream().cuda_stream
+    batch = args.workload == "config4"
+    if batch:
+        from stereo_reconstruction_amd.sharding import lpt_assign
+        from stereo_reconstruction_amd.synthetic import TRAINING_H
+        bs, cost, max_d = 7, "ssd", 256
+        shapes = [(w, h) for _, w, h, _ in TRAINING_H]
+        mine = lpt_assign([w * h * max_d for w, h in shapes], world)[rank]
+        pairs = []
+        for i in mine:
+            l, r, _ = make_pair(shapes[i][0], shapes[i][1], max_d, 100 + i)
+            pairs.append((torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev),
+                          torch.empty((shapes[i][1], shapes[i][0]), dtype=torch.float32, device=dev)))
+        width, height = shapes[mine[0]] if mine else shapes[0]
+        left, right = (pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()) if pairs else (None, None)
+        t_out = pairs[0][2] if pairs else None
+        hyps_total = float(sum(w * h * max_d for w, h in shapes))
+    else:
+        width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
+        left, right, _gt = make_pair(width, height, max_d, seed + rank)
+        t_out = torch.empty((height, width), dtype=torch.float32, device=dev)
+        pairs = [(torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev), t_out)]
+        hyps_total = float(width) * height * max_d * world   # one pair per rank (weak scaling)
+    params = ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
 
     def step():
-        ctx.search_device(params, t_left, t_right, t_out, stream)
+        for tl, tr, to in pairs:   # whole pairs per rank, no collective on the data path
+            ctx.search_device(params, tl, tr, to, stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,8 +134,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    hyps = float(width) * height * max_d          # H*W*D per pair
-    value = hyps * args.steps * world / elapsed / 1e6
+    value = hyps_total * args.steps / elapsed / 1e6     # H*W*D hypotheses of the whole job
 
     # dominant kernel, timed alone with HIP events on the launch stream
     kernel_ms = None
@@ -127,7 +146,9 @@ def main():
         acc.append(ctx.last_kernel_ms())
     ctx.set_profiling(False)
     kernel_ms = float(np.mean(acc))
-    alg_bytes = 3.0 * height * width + 3.0 * right.shape[0] * right.shape[1] + 4.0 * height * width
+    # the event pair brackets the LAST pair's marching kernel of a step
+    lw, lh = pairs[-1][0].shape[1], pairs[-1][0].shape[0]
+    alg_bytes = 3.0 * lh * lw + 3.0 * pairs[-1][1].shape[0] * pairs[-1][1].shape[1] + 4.0 * lh * lw
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     out = {
@@ -139,13 +160,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if batch else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
+        "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
+                                "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
+                               "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
                                % (args.workload, width, height, bs, bs, cost.upper(), max_d),
-                   "pairs_per_step": world, "sharding": "independent pairs, no collective"},
+                   "pairs_per_step": 15 if batch else world, "sharding": "independent pairs, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                      "kernel": info["kernel"], "kernel_ms": round(kernel_ms, 4),

@@ -183,7 +183,7 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     int rc = run_search(ctx, &q, L, R, out, out_stride, s);
     if (rc != WS_OK) return rc;
     const int sel_pitch = (R->width + 63) & ~63;
-    if ((rc = ensure(ctx, ctx->sel, (size_t)sel_pitch * R->height)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->sel, (size_t)sel_pitch * (smooth_sel_rows(R->height) + 64))) != WS_OK) return rc;
     GenericArgs ga{};
     ga.L = L->data; ga.R = R->data;
     ga.w1 = L->width; ga.h1 = L->height; ga.s1 = L->stride;
@@ -214,6 +214,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
 
     Canon c{};
     MarchLaunch m{};
+    Plane ring_a{}, ring_b{};
     bool march = make_canon(p, L, R, &c) &&
                  march_plan(c, ctx->num_cus, ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads, &m);
     if (march) {
@@ -226,6 +227,8 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         pa.data = static_cast<uint32_t *>(ctx->plane_a.p);
         pb.data = static_cast<uint32_t *>(ctx->plane_b.p);
         pbi.data = static_cast<uint32_t *>(ctx->bias.p);
+        ring_a = pa;
+        ring_b = pb;
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
         WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, pa, ib->data, ib->width,
@@ -254,7 +257,10 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ctx->last_lds = 0;
     }
     // everything the marching kernel does not own: border ring, rows past min(h1,h2), or all of it
-    WS_HIP(ctx, launch_generic(ga, s));
+    if (march && p->view == WS_VIEW_RIGHT)
+        WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, s));
+    else
+        WS_HIP(ctx, launch_generic(ga, s));
     if (p->subpixel) WS_HIP(ctx, launch_refine(ga, s));
     return WS_OK;
 }

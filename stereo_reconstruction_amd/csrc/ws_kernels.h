@@ -76,9 +76,14 @@ struct GenericArgs {
     int out_pitch;
 };
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
+// Right-view border ring on the packed (mirrored) planes: one wave per pixel, lanes over d.
+hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
+                       hipStream_t s);
 // Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
+// rows the sel plane must be allocated with (whole LDS chunks are copied)
+int smooth_sel_rows(int rows);
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st);
 // float32 -> float64 widening for CV_64F outputs
 hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,

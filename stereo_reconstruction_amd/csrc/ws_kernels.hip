@@ -815,6 +815,107 @@ __global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
     g.out[(size_t)y * g.out_pitch + x] = val;
 }
 
+// ------------------------------------------------------------------------------------------
+// right-view border ring: clipped windows (BlockSearch.cpp:116-123), one wave per pixel
+//
+// The marching kernel owns the pixels whose (bs-1)^2 window is complete.  On the ring the window
+// is clipped by the image border, so its size changes from pixel to pixel; there are only
+// ~2*half*(W+H) such pixels.  One wavefront takes one pixel: the 64 lanes take 64 consecutive
+// disparities at a time (consecutive lanes read consecutive target pixels), every lane sums its
+// own window on the packed planes, keeps its best candidate, and a wave-wide min over
+// (cost, d) keys -- butterfly of shuffles -- picks the winner with the reference's tie rule.
+// ------------------------------------------------------------------------------------------
+struct RingArgs {
+    const uint32_t *A;
+    const uint32_t *B;
+    int pitch_a, pad_a, pitch_b, pad_b;
+    int wa, ha, wb;          // canonical plane sizes: A = mirrored right image, B = mirrored left
+    int height;              // min(h1, h2)
+    int half, boff, d_lo, d_hi;
+    int ssd, centred;
+    int skip_x0, skip_x1, skip_y0, skip_y1; // marching interior, ORIGINAL coordinates
+    float *out;
+    int out_pitch;
+};
+
+__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    GenericArgs e{}; // only the skip rectangle is used by ring_pixel
+    e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
+    int x, y;
+    if (!ring_pixel(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
+    const int xm = g.wa - 1 - x; // canonical (mirrored) column
+    float val = 0.0f;
+    const uint32_t black = g.centred ? kCentre : 0u;
+    if (y < g.height && g.A[(size_t)y * g.pitch_a + xm + g.pad_a] != black) {
+        const int left = min(x, g.half), right = min(g.wa - x - 1, g.half);
+        const int up = min(y, g.half), down = min(g.ha - y - 1, g.half);
+        const int ww = left + right, wh = up + down;
+        // candidates: d_lo <= d <= d_hi with x + d + right < w1 (BlockSearch.cpp:147-149)
+        const int d_end = min(g.d_hi, g.wb - right - x - 1);
+        long long best = LLONG_MAX;
+        if (ww > 0 && wh > 0) {
+            const int c0 = xm - right + 1; // first window column, canonical
+            const uint32_t *arow0 = g.A + (size_t)(y - up) * g.pitch_a + c0 + g.pad_a;
+            for (int d = g.d_lo + lane; d <= d_end; d += 64) {
+                const uint32_t *brow0 = g.B + (size_t)(y - up) * g.pitch_b + (c0 - d + g.boff + g.pad_b);
+                int32_t cost = 0;
+                for (int r = 0; r < wh; ++r) {
+                    const uint32_t *pa = arow0 + (size_t)r * g.pitch_a;
+                    const uint32_t *pb = brow0 + (size_t)r * g.pitch_b;
+                    if (!g.ssd) {
+                        uint32_t acc = 0;
+                        for (int i = 0; i < ww; ++i) acc = pix_sad(pa[i], pb[i], acc);
+                        cost += (int32_t)acc;
+                    } else if (g.centred) {
+                        uint32_t bb = 0, ab = 0; // sum (a-b)^2 = sum a^2 + [sum b^2 - 2 sum ab]; sum a^2 is the same for every d
+                        for (int i = 0; i < ww; ++i) {
+                            bb = pix_dot<true>(pb[i], pb[i], bb);
+                            ab = pix_dot<true>(pa[i], pb[i], ab);
+                        }
+                        cost += (int32_t)bb - 2 * (int32_t)ab;
+                    } else {
+                        uint32_t bb = 0, ab = 0;
+                        for (int i = 0; i < ww; ++i) {
+                            bb = pix_dot<false>(pb[i], pb[i], bb);
+                            ab = pix_dot<false>(pa[i], pb[i], ab);
+                        }
+                        cost += (int32_t)bb - 2 * (int32_t)ab;
+                    }
+                }
+                const long long key = ((long long)cost << 32) | (uint32_t)d; // ties: smaller d
+                best = min(best, key);
+            }
+        }
+        // wave-wide min: butterfly over the 64 lanes
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+        val = best == LLONG_MAX ? -(float)x : (float)(uint32_t)(best & 0xffffffffll);
+    }
+    if (lane == 0) g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
+hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
+                       hipStream_t s)
+{
+    RingArgs g{};
+    g.A = a.data; g.B = b.data;
+    g.pitch_a = a.pitch; g.pad_a = a.pad; g.pitch_b = b.pitch; g.pad_b = b.pad;
+    g.wa = c.wa; g.ha = c.ha; g.wb = c.wb;
+    g.height = std::min(c.ha, c.hb);
+    g.half = c.wh / 2; // right view: window (bs-1)^2 = (2*half)^2
+    g.boff = c.boff; g.d_lo = c.d_lo; g.d_hi = c.d_hi;
+    g.ssd = c.ssd; g.centred = march_centred(c);
+    g.skip_x0 = skip.skip_x0; g.skip_x1 = skip.skip_x1; g.skip_y0 = skip.skip_y0; g.skip_y1 = skip.skip_y1;
+    g.out = out; g.out_pitch = out_pitch;
+    const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
+    const long long n = (long long)c.wa * c.ha - (inside > 0 ? inside : 0);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ws_ring_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s)
 {
     const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
@@ -899,6 +1000,7 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s)
 // order, solved row by row with a scan over function composition.
 // ------------------------------------------------------------------------------------------
 constexpr uint8_t kSelFixed = 0x80; // value in the map is final; otherwise bits 0..2 = t_0..t_2
+constexpr uint8_t kSelZero = 0x40;  // with kSelFixed: that final value is 0
 
 __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArgs g, double s,
                                                                 uint8_t *__restrict__ sel, int sel_pitch)
@@ -962,6 +1064,7 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
         }
     }
     *o = val;
+    if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
     sel[(size_t)y * sel_pitch + x] = code;
 }
 
@@ -1041,16 +1144,107 @@ __global__ void __launch_bounds__(1024) ws_smooth_resolve_kernel(float *out, int
     }
 }
 
+// The same recurrence for images up to 64 * PER columns wide, on ONE wavefront: every lane owns
+// PER consecutive columns, keeps the previous row's zero flags in a 64-bit mask, and the row scan
+// is six shuffles -- no barrier.  The codes arrive in chunks of rows by LDS-DMA, one chunk ahead,
+// so the serial walk over the rows never waits for HBM.
+template <int PER>
+__global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, int out_pitch, int w, int rows,
+                                                                    const uint8_t *__restrict__ sel, int sel_pitch,
+                                                                    int chunk_rows)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    extern __shared__ uint4 ws_smem4[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
+    const int lane = threadIdx.x;
+    const int x0 = lane * PER;
+    const int chunk_bytes = chunk_rows * sel_pitch; // multiple of 1024: sel_pitch % 64 == 0, chunk_rows % 16 == 0
+    const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    // the sel plane is allocated with (rows rounded up to chunk_rows) rows, so whole chunks may be copied
+    for (int o = lane * 16; o < chunk_bytes; o += 1024)
+        __builtin_amdgcn_global_load_lds((glb_void *)(sel + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
+    unsigned long long zprev = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // chunk c has landed
+        const uint8_t *cur_buf = lds + (c & 1) * chunk_bytes;
+        if (c + 1 < nchunks) {
+            const uint8_t *src = sel + (size_t)(c + 1) * chunk_bytes;
+            uint8_t *dst = lds + ((c + 1) & 1) * chunk_bytes;
+            for (int o = lane * 16; o < chunk_bytes; o += 1024)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
+        }
+        const int y_end = min((c + 1) * chunk_rows, rows);
+        for (int y = c * chunk_rows; y < y_end; ++y) {
+            const uint8_t *srow = cur_buf + (y - c * chunk_rows) * sel_pitch + x0;
+            uint32_t cur[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) cur[k] = (x0 + k < w) ? srow[k] : kSelFixed;
+            uint32_t f = 2;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t cc = cur[k];
+                const uint32_t zu = (uint32_t)(zprev >> k) & 1u;
+                const uint32_t zf = (cc >> 6) & 1u;
+                const uint32_t gm = (cc & kSelFixed) ? (zf | (zf << 1))
+                                                     : ((((cc >> zu) & 1u) ^ 1u) | ((((cc >> (zu + 1)) & 1u) ^ 1u) << 1));
+                f = compose2(f, gm);
+            }
+            uint32_t incl = f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t prev = __shfl_up(incl, off, 64);
+                if (lane >= off) incl = compose2(prev, incl);
+            }
+            uint32_t excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 2;
+            uint32_t b = excl & 1u; // column 0 has no left neighbour
+            unsigned long long znew = 0;
+            float *orow = out + (size_t)y * out_pitch + x0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t cc = cur[k];
+                uint32_t z;
+                if (cc & kSelFixed) {
+                    z = (cc >> 6) & 1u;
+                } else {
+                    const uint32_t kk = ((uint32_t)(zprev >> k) & 1u) + b;
+                    z = ((cc >> kk) & 1u) ^ 1u;
+                    if (z) orow[k] = 0.0f;
+                }
+                znew |= (unsigned long long)z << k;
+                b = z;
+            }
+            zprev = znew;
+        }
+    }
+}
+
+int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
+
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st)
 {
     dim3 grid(ceil_div(g.w2, 256), g.h2);
     hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int rows = g.view == 1 ? std::min(g.h1, g.h2) : std::min(g.h1, g.h2);
-    const size_t lds = (size_t)((g.w2 + 3) & ~3) + 16 * sizeof(uint32_t);
-    hipLaunchKernelGGL(ws_smooth_resolve_kernel, dim3(1), dim3(1024), lds, st, g.out, g.out_pitch, g.w2, rows, sel,
-                       sel_pitch);
+    const int rows = std::min(g.h1, g.h2);
+    const int per = ceil_div(g.w2, 64);
+    // rows per LDS chunk: two chunks in at most 64 KB, a multiple of 16 rows (whole 1 KB DMA pieces)
+    int chunk = (32768 / sel_pitch) / 16 * 16;
+    if (chunk > 64) chunk = 64;
+    const size_t wl = (size_t)2 * chunk * sel_pitch;
+    if (per <= 8 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<8>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else if (per <= 16 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<16>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else if (per <= 32 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<32>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else {
+        const size_t lds = (size_t)((g.w2 + 3) & ~3) + 16 * sizeof(uint32_t);
+        hipLaunchKernelGGL(ws_smooth_resolve_kernel, dim3(1), dim3(1024), lds, st, g.out, g.out_pitch, g.w2, rows, sel,
+                           sel_pitch);
+    }
     return hipGetLastError();
 }
 
