@@ -77,12 +77,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    # WS_BENCH_REHEARSE=1: rehearse the N>1 code path on a box with fewer GPUs than ranks (all
+    # ranks share the devices round-robin, gloo instead of RCCL).  Never used for reported numbers.
+    rehearse = os.environ.get("WS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     dev = torch.device("cuda", local_rank)
     ctx = ws.WindowSearch(local_rank)
@@ -130,7 +138,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -151,6 +159,15 @@ def main():
     alg_bytes = 3.0 * lh * lw + 3.0 * pairs[-1][1].shape[0] * pairs[-1][1].shape[1] + 4.0 * lh * lw
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc (one pass per
+    # counter) and committed; bench.py does not run the profiler itself
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01", "traffic_%s.json" % args.workload)
+    if os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        if tj.get("kernel") == info["kernel"]:
+            traffic = tj["hbm_bytes_per_launch"]
+
     out = {
         "metric": "Mdisparities/s (HxWxD / s) on Middlebury-H pairs",
         "value": round(value, 1),
@@ -163,14 +180,14 @@ def main():
         "scaling": "strong" if batch else "weak",
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
+        "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
         "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
                                 "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
                                "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
                                % (args.workload, width, height, bs, bs, cost.upper(), max_d),
                    "pairs_per_step": 15 if batch else world, "sharding": "independent pairs, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": info["kernel"], "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": alg_bytes,
                      "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "

@@ -144,6 +144,19 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left,
                     const ws_image *right, void *out, int out_stride, int out_dtype);
 int ws_wait(ws_context *ctx);
 
+/*
+ * The back-projection the caller of the hot path applies to its result:
+ *   cv::warpPerspective(disparityMap_rect, disparityMapLeft, H_.inv(), size, INTER_NEAREST)
+ *   (rectification.cpp:70-75, :82-87).  `m` is the 3x3 matrix handed to warpPerspective (row-major,
+ *   i.e. H_.inv()); like OpenCV the call inverts it and gathers dst(x,y) = src(round(M^-1 (x,y,1))),
+ *   0 outside.  For already rectified pairs m is the identity and this is a copy.
+ */
+int ws_warp_nearest_host(ws_context *ctx, const double *src, int src_w, int src_h, int src_stride,
+                         const double m[9], double *dst, int dst_w, int dst_h, int dst_stride);
+int ws_warp_nearest_device(ws_context *ctx, const float *src_dev, int src_w, int src_h, int src_stride,
+                           const double m[9], float *dst_dev, int dst_w, int dst_h, int dst_stride,
+                           void *stream);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* hipEvent pair on `stream` (NULL = context stream): begin, enqueue work, end -> elapsed ms. */
 int ws_timer_begin(ws_context *ctx, void *stream);

@@ -136,3 +136,40 @@ def evaldisp(disp, gt, mask, badthresh, maxdisp, rounddisp=0):
                               d.shape[0], badthresh, maxdisp, int(rounddisp), res))
     return {"n": int(res[0]), "bad": res[1], "invalid": res[2], "total_bad": res[3],
             "avg_err": res[4], "valid": res[5]}
+
+
+def _inv3(m):
+    """3x3 inverse by adjugate / determinant (the closed form cv::invert uses for 3x3)."""
+    m = np.asarray(m, dtype=np.float64).reshape(9)
+    d = (m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6])
+         + m[2] * (m[3] * m[7] - m[4] * m[6]))
+    r = 1.0 / d
+    return np.array([(m[4] * m[8] - m[5] * m[7]) * r, (m[2] * m[7] - m[1] * m[8]) * r, (m[1] * m[5] - m[2] * m[4]) * r,
+                     (m[5] * m[6] - m[3] * m[8]) * r, (m[0] * m[8] - m[2] * m[6]) * r, (m[2] * m[3] - m[0] * m[5]) * r,
+                     (m[3] * m[7] - m[4] * m[6]) * r, (m[1] * m[6] - m[0] * m[7]) * r, (m[0] * m[4] - m[1] * m[3]) * r])
+
+
+def warp_nearest(src, matrix, dst_shape):
+    """cv::warpPerspective(src, dst, matrix, dst.size(), INTER_NEAREST) as ImageRectifier calls it with
+    matrix = H_.inv() (rectification.cpp:70-75, :82-87).  OpenCV is un-vendored in the reference; this
+    restates its 4.x behaviour: invert the matrix, evaluate per 64-column block
+    (M0*xb + M1*y + M2 + M0*x1) * (1/W), round half to even, constant 0 outside.  PARITY UNPINNED."""
+    src = np.asarray(src, dtype=np.float64)
+    m = _inv3(matrix)
+    h, w = dst_shape
+    out = np.zeros((h, w), dtype=np.float64)
+    xs = np.arange(w)
+    xb, x1 = (xs & ~63).astype(np.float64), (xs & 63).astype(np.float64)
+    for y in range(h):
+        X0 = m[0] * xb + m[1] * y + m[2]
+        Y0 = m[3] * xb + m[4] * y + m[5]
+        W = m[6] * xb + m[7] * y + m[8] + m[6] * x1
+        with np.errstate(divide="ignore"):
+            W = np.where(W != 0, 1.0 / W, 0.0)
+        fx = np.clip((X0 + m[0] * x1) * W, -2147483648.0, 2147483647.0)
+        fy = np.clip((Y0 + m[3] * x1) * W, -2147483648.0, 2147483647.0)
+        X = np.rint(fx).astype(np.int64)
+        Y = np.rint(fy).astype(np.int64)
+        ok = (X >= 0) & (X < src.shape[1]) & (Y >= 0) & (Y < src.shape[0])
+        out[y, ok] = src[Y[ok], X[ok]]
+    return out

@@ -36,7 +36,8 @@ ERRORS = {-1: "WS_ERR_ARG", -2: "WS_ERR_GEOMETRY", -3: "WS_ERR_UNSUPPORTED", -4:
 
 # every symbol include/ws_stereo.h declares (tests check the library exports all of them)
 EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_last_error",
-           "ws_device_count", "ws_validate", "ws_plan", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait",
+           "ws_device_count", "ws_validate", "ws_plan", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait", "ws_warp_nearest_host",
+           "ws_warp_nearest_device",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
            "ws_last_launch_info", "ws_set_tuning",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_calib_read", "ws_evaldisp"]
@@ -123,6 +124,8 @@ def load_library(build_if_missing=False):
     lib.ws_search_device.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, vp]
     lib.ws_enqueue_host.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, ci]
     lib.ws_wait.argtypes = [vp]
+    lib.ws_warp_nearest_host.argtypes = [vp, vp, ci, ci, ci, P(ctypes.c_double), vp, ci, ci, ci]
+    lib.ws_warp_nearest_device.argtypes = [vp, vp, ci, ci, ci, P(ctypes.c_double), vp, ci, ci, ci, vp]
     lib.ws_timer_begin.argtypes = [vp, vp]
     lib.ws_timer_end.argtypes = [vp, vp, P(ctypes.c_float)]
     lib.ws_set_profiling.argtypes = [vp, ci]
@@ -224,6 +227,15 @@ class WindowSearch:
         self._check(self._lib.ws_search_device(self._h, ctypes.byref(params), ctypes.byref(Li),
                                                ctypes.byref(Ri), out_t.data_ptr(), out_t.stride(0),
                                                ctypes.c_void_p(stream or 0)))
+
+    def warp_nearest(self, src, matrix, dst_shape):
+        """cv::warpPerspective(src, dst, matrix, dst_size, INTER_NEAREST) on a float64 map."""
+        a = np.ascontiguousarray(src, dtype=np.float64)
+        m = (ctypes.c_double * 9)(*np.asarray(matrix, dtype=np.float64).reshape(9))
+        out = np.empty(dst_shape, dtype=np.float64)
+        self._check(self._lib.ws_warp_nearest_host(self._h, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1],
+                                                   m, out.ctypes.data, out.shape[1], out.shape[0], out.shape[1]))
+        return out
 
     def timer_begin(self, stream=None):
         self._check(self._lib.ws_timer_begin(self._h, ctypes.c_void_p(stream or 0)))

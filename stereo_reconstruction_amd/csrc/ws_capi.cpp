@@ -501,6 +501,66 @@ int ws_wait(ws_context *ctx)
     return WS_OK;
 }
 
+static bool invert3x3(const double m[9], double out[9])
+{
+    // closed form (adjugate / determinant), as cv::invert does for 3x3 matrices
+    const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                     m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0.0) return false;
+    const double r = 1.0 / d;
+    out[0] = (m[4] * m[8] - m[5] * m[7]) * r;
+    out[1] = (m[2] * m[7] - m[1] * m[8]) * r;
+    out[2] = (m[1] * m[5] - m[2] * m[4]) * r;
+    out[3] = (m[5] * m[6] - m[3] * m[8]) * r;
+    out[4] = (m[0] * m[8] - m[2] * m[6]) * r;
+    out[5] = (m[2] * m[3] - m[0] * m[5]) * r;
+    out[6] = (m[3] * m[7] - m[4] * m[6]) * r;
+    out[7] = (m[1] * m[6] - m[0] * m[7]) * r;
+    out[8] = (m[0] * m[4] - m[1] * m[3]) * r;
+    return true;
+}
+
+int ws_warp_nearest_device(ws_context *ctx, const float *src_dev, int src_w, int src_h, int src_stride,
+                           const double m[9], float *dst_dev, int dst_w, int dst_h, int dst_stride, void *stream)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (!src_dev || !dst_dev || !m || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 ||
+        src_stride < src_w || dst_stride < dst_w)
+        return fail(ctx, WS_ERR_ARG, "bad warp arguments");
+    double inv[9];
+    if (!invert3x3(m, inv)) return fail(ctx, WS_ERR_ARG, "singular warp matrix");
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    WS_HIP(ctx, launch_warp(src_dev, src_w, src_h, src_stride, dst_dev, dst_w, dst_h, dst_stride, inv, s));
+    return WS_OK;
+}
+
+int ws_warp_nearest_host(ws_context *ctx, const double *src, int src_w, int src_h, int src_stride,
+                         const double m[9], double *dst, int dst_w, int dst_h, int dst_stride)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (!src || !dst || !m || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_stride < src_w ||
+        dst_stride < dst_w)
+        return fail(ctx, WS_ERR_ARG, "bad warp arguments");
+    // disparity maps are integer valued (or f32 sub-pixel): f32 on the device, CV_64F at the boundary
+    std::vector<float> hs((size_t)src_w * src_h), hd((size_t)dst_w * dst_h);
+    for (int y = 0; y < src_h; ++y)
+        for (int x = 0; x < src_w; ++x) hs[(size_t)y * src_w + x] = (float)src[(size_t)y * src_stride + x];
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_out, hs.size() * 4)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out64, hd.size() * 4)) != WS_OK) return rc;
+    WS_HIP(ctx, hipMemcpyAsync(ctx->d_out.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = ws_warp_nearest_device(ctx, static_cast<const float *>(ctx->d_out.p), src_w, src_h, src_w, m,
+                                static_cast<float *>(ctx->d_out64.p), dst_w, dst_h, dst_w, ctx->stream);
+    if (rc != WS_OK) return rc;
+    WS_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->d_out64.p, hd.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int y = 0; y < dst_h; ++y)
+        for (int x = 0; x < dst_w; ++x) dst[(size_t)y * dst_stride + x] = (double)hd[(size_t)y * dst_w + x];
+    return WS_OK;
+}
+
 int ws_timer_begin(ws_context *ctx, void *stream)
 {
     if (!ctx) return WS_ERR_ARG;

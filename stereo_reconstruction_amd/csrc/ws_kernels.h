@@ -85,6 +85,9 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st);
+// nearest-neighbour perspective warp of a float map; minv maps destination -> source pixels
+hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
+                       const double minv[9], hipStream_t s);
 // float32 -> float64 widening for CV_64F outputs
 hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
                         hipStream_t s);

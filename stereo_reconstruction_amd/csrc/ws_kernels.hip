@@ -211,7 +211,7 @@ struct MarchArgs {
     int wx0, wy0, boff;
     int d_lo, d_hi, b_lo, b_hi;
     int ox0, ox1, oy0, oy1;
-    int strip_rows;
+    int strip_rows, tiles, strips;
     int prefer_large, mirror, fallback_neg;
     int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
 };
@@ -346,8 +346,14 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
     slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
 
-    const int tile_x0 = g.ox0 + blockIdx.x * tx;
-    const int ys = g.oy0 + blockIdx.y * g.strip_rows;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so ids b and b+8 share one.  Give every XCD a contiguous range of (strip, tile) pairs:
+    // the tiles of a strip overlap in the target-image columns they read and then hit the same L2.
+    const int nblk = gridDim.x; // padded to a multiple of 8 by the launcher
+    const int logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    if (logical >= g.tiles * g.strips) return; // uniform per workgroup
+    const int tile_x0 = g.ox0 + (logical % g.tiles) * tx;
+    const int ys = g.oy0 + (logical / g.tiles) * g.strip_rows;
     const int ye = min(ys + g.strip_rows, g.oy1);
     if (ys >= ye) return; // uniform per workgroup
 
@@ -689,6 +695,8 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.oy0 = c.oy0;
     g.oy1 = c.oy1;
     g.strip_rows = m.strip_rows;
+    g.tiles = m.tiles;
+    g.strips = m.strips;
     g.prefer_large = c.prefer_large;
     g.mirror = c.mirror;
     g.fallback_neg = c.fallback_neg;
@@ -698,7 +706,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
                                              (int)m.lds_bytes);
         if (err != hipSuccess) return err;
     }
-    dim3 grid(m.tiles, m.strips);
+    dim3 grid(round_up(m.tiles * m.strips, 8));
     hipLaunchKernelGGL(e->fn, grid, dim3(m.threads), m.lds_bytes, s, g);
     return hipGetLastError();
 }
@@ -1245,6 +1253,51 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
         hipLaunchKernelGGL(ws_smooth_resolve_kernel, dim3(1), dim3(1024), lds, st, g.out, g.out_pitch, g.w2, rows, sel,
                            sel_pitch);
     }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// back-projection of a disparity map: cv::warpPerspective(map, dst, M, dst.size(), INTER_NEAREST)
+// as ImageRectifier::computeDisparityMapLeft/Right call it with M = H_.inv()
+// (rectification.cpp:70-75, :82-87).  OpenCV (un-vendored, 4.x semantics restated): M is inverted,
+// destination pixel (x, y) reads source pixel (cvRound(X/W), cvRound(Y/W)) of (X,Y,W) = M^-1 (x,y,1),
+// evaluated per 64-column block as (M0*xb + M1*y + M2 + M0*x1) * (1/W); outside -> 0.
+// ------------------------------------------------------------------------------------------
+struct WarpArgs {
+    const float *src;
+    int sw, sh, sp;
+    float *dst;
+    int dw, dh, dp;
+    double m[9]; // already inverted: destination -> source
+};
+
+__global__ void __launch_bounds__(256) ws_warp_kernel(const WarpArgs g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= g.dw || y >= g.dh) return;
+    const int xb = x & ~63, x1 = x & 63;
+    const double X0 = g.m[0] * xb + g.m[1] * y + g.m[2];
+    const double Y0 = g.m[3] * xb + g.m[4] * y + g.m[5];
+    const double W0 = g.m[6] * xb + g.m[7] * y + g.m[8];
+    double W = W0 + g.m[6] * x1;
+    W = W != 0.0 ? 1.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + g.m[0] * x1) * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + g.m[3] * x1) * W));
+    const long long X = __double2ll_rn(fX), Y = __double2ll_rn(fY); // round half to even, like cvRound
+    float v = 0.0f;
+    if (X >= 0 && X < g.sw && Y >= 0 && Y < g.sh) v = g.src[(size_t)Y * g.sp + X];
+    g.dst[(size_t)y * g.dp + x] = v;
+}
+
+hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
+                       const double minv[9], hipStream_t s)
+{
+    WarpArgs g{};
+    g.src = src; g.sw = sw; g.sh = sh; g.sp = sp;
+    g.dst = dst; g.dw = dw; g.dh = dh; g.dp = dp;
+    for (int i = 0; i < 9; ++i) g.m[i] = minv[i];
+    hipLaunchKernelGGL(ws_warp_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 

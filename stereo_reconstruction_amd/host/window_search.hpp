@@ -182,9 +182,10 @@ private:
     Device &device_;
 };
 
-// The boundary methods of ImageRectifier (rectification.cpp:66-88, getters :515-521) for pairs
-// that are already rectified (Middlebury): the homography is the identity, so the
-// warpPerspective(.., H_.inv(), INTER_NEAREST) of the reference is a copy.
+// The boundary methods of ImageRectifier (rectification.cpp:66-88, getters :515-521): block search
+// on the rectified pair, then cv::warpPerspective(map, H_.inv(), original size, INTER_NEAREST) back
+// to the original frame (the reference uses H_ for both views).  For pairs that are already
+// rectified (Middlebury) leave H at the identity: the warp is then a copy and is skipped.
 class RectifiedPair {
 public:
     RectifiedPair(const Image8UC3 &leftRectified, const Image8UC3 &rightRectified,
@@ -192,23 +193,51 @@ public:
         : left_(leftRectified), right_(rightRectified), device_(device)
     {
     }
+    // H = the rectifying homography H_ (row-major 3x3); rows/cols = size of the original images
+    void setHomography(const double H[9], int leftRows, int leftCols, int rightRows, int rightCols)
+    {
+        for (int i = 0; i < 9; ++i) H_[i] = H[i];
+        rows_[0] = leftRows; cols_[0] = leftCols; rows_[1] = rightRows; cols_[1] = rightCols;
+        warp_ = true;
+    }
     void computeDisparityMapLeft(int blockSize, int minDisparity, int maxDisparity, double smoothFactor)
     {
-        disparityMapLeft = BlockSearch(left_, right_, blockSize, minDisparity, maxDisparity, device_)
-                               .computeDisparityMapLeft(smoothFactor);
+        MatF64 rect = BlockSearch(left_, right_, blockSize, minDisparity, maxDisparity, device_)
+                          .computeDisparityMapLeft(smoothFactor);
+        disparityMapLeft = warp_ ? warpBack(rect, rows_[0], cols_[0]) : rect;
     }
     void computeDisparityMapRight(int blockSize, int minDisparity, int maxDisparity, double smoothFactor,
                                   bool varBlock = false, double thres = 10.0) // default thres: rectification.hpp:66
     {
-        disparityMapRight = BlockSearch(left_, right_, blockSize, minDisparity, maxDisparity, device_)
-                                .computeDisparityMapRight(smoothFactor, varBlock, thres);
+        MatF64 rect = BlockSearch(left_, right_, blockSize, minDisparity, maxDisparity, device_)
+                          .computeDisparityMapRight(smoothFactor, varBlock, thres);
+        disparityMapRight = warp_ ? warpBack(rect, rows_[1], cols_[1]) : rect;
     }
     const MatF64 &getDisparityMapLeft() const { return disparityMapLeft; }
     const MatF64 &getDisparityMapRight() const { return disparityMapRight; }
 
 private:
+    MatF64 warpBack(const MatF64 &rect, int rows, int cols)
+    {
+        // H_.inv() by adjugate / determinant, handed on as the warpPerspective matrix
+        const double *m = H_;
+        const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                         m[2] * (m[3] * m[7] - m[4] * m[6]);
+        const double r = 1.0 / d;
+        const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) * r, (m[2] * m[7] - m[1] * m[8]) * r, (m[1] * m[5] - m[2] * m[4]) * r,
+                               (m[5] * m[6] - m[3] * m[8]) * r, (m[0] * m[8] - m[2] * m[6]) * r, (m[2] * m[3] - m[0] * m[5]) * r,
+                               (m[3] * m[7] - m[4] * m[6]) * r, (m[1] * m[6] - m[0] * m[7]) * r, (m[0] * m[4] - m[1] * m[3]) * r};
+        MatF64 out(rows, cols);
+        const int rc = ws_warp_nearest_host(device_.get(), rect.ptr(), rect.cols, rect.rows, rect.cols, inv,
+                                            out.ptr(), cols, rows, cols);
+        if (rc != WS_OK) throw Error(rc, ws_last_error(device_.get()));
+        return out;
+    }
     Image8UC3 left_, right_;
     Device &device_;
+    double H_[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rows_[2] = {0, 0}, cols_[2] = {0, 0};
+    bool warp_ = false;
     MatF64 disparityMapLeft, disparityMapRight;
 };
 

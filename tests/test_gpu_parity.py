@@ -158,6 +158,21 @@ def test_reference_pipeline_call_on_teddy_sized_pair(wslib, gpu_ctx, oracle):
     assert np.array_equal(got[:12], band[:12])       # raster dependency: the oracle must start at row 0
 
 
+def test_warp_back_to_the_original_frame(wslib, gpu_ctx, oracle):
+    """The warpPerspective(.., H_.inv(), INTER_NEAREST) of rectification.cpp:70-75 on the device."""
+    rng = np.random.default_rng(2)
+    disp = rng.integers(0, 200, size=(90, 140)).astype(np.float64)
+    ident = np.eye(3)
+    assert np.array_equal(gpu_ctx.warp_nearest(disp, ident, (90, 140)), disp)      # rectified pairs: a copy
+    for m in (np.array([[1.02, 0.01, -3.0], [-0.015, 0.98, 2.5], [1e-5, -2e-5, 1.0]]),
+              np.array([[0.5, 0.0, 10.0], [0.0, 0.5, -4.0], [0.0, 0.0, 1.0]]),
+              np.array([[1.0, 0.2, 0.0], [0.0, 1.0, 0.0], [0.0, 1e-3, 1.0]])):
+        got = gpu_ctx.warp_nearest(disp, m, (100, 150))
+        want = oracle.warp_nearest(disp, m, (100, 150))
+        assert np.array_equal(got, want)
+        assert (got != 0).any()
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
