@@ -157,6 +157,28 @@ int ws_warp_nearest_device(ws_context *ctx, const float *src_dev, int src_w, int
                            const double m[9], float *dst_dev, int dst_w, int dst_h, int dst_stride,
                            void *stream);
 
+/* ---- consumers of the map: the Reconstruction side of the call surface ------------------- */
+/*
+ * removeDisparityOutliers(disparityMap, kernelSize, thrFront, thrBack)  (reconstruction.cpp:5-18,
+ * main.cpp:53): k x k cv::blur (normalised box, BORDER_REFLECT_101), then every value above
+ * thrFront * blurred or below thrBack * blurred is replaced by the blurred one.  In place, float32.
+ */
+int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int height, int stride,
+                                 int kernel_size, float thr_front, float thr_back);
+/* convertDisparityToDepth(dispImage, focalLength, baseline)  (reconstruction.cpp:30-43): f*b/d, 0 -> -inf */
+int ws_convert_disparity_to_depth(ws_context *ctx, const float *disp, int width, int height, int stride,
+                                  float focal_length, float baseline, float *depth, int depth_stride);
+/*
+ * The back-projection loop of reconstruction() (reconstruction.cpp:152-196): positions = w*h x 4
+ * floats (x_cam, y_cam, depth, 1; all -inf where depth is -inf), colors = w*h x 4 bytes (R,G,B,255).
+ * intrinsics = row-major 3x3 (fx, 0, cx, 0, fy, cy, ...).
+ */
+int ws_back_project(ws_context *ctx, const float *depth, int width, int height, int stride,
+                    const float intrinsics[9], const ws_image *bgr, float *positions, uint8_t *colors);
+/* WriteMesh (reconstruction.cpp:72-149): COFF text file; host only. */
+int ws_write_mesh_off(const char *path, const float *positions, const uint8_t *colors, int width,
+                      int height, float edge_threshold);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* hipEvent pair on `stream` (NULL = context stream): begin, enqueue work, end -> elapsed ms. */
 int ws_timer_begin(ws_context *ctx, void *stream);

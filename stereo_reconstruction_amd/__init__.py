@@ -37,7 +37,8 @@ ERRORS = {-1: "WS_ERR_ARG", -2: "WS_ERR_GEOMETRY", -3: "WS_ERR_UNSUPPORTED", -4:
 # every symbol include/ws_stereo.h declares (tests check the library exports all of them)
 EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_last_error",
            "ws_device_count", "ws_validate", "ws_plan", "ws_search_host", "ws_search_device", "ws_enqueue_host", "ws_wait", "ws_warp_nearest_host",
-           "ws_warp_nearest_device",
+           "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
+           "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
            "ws_last_launch_info", "ws_set_tuning",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_calib_read", "ws_evaldisp"]
@@ -124,6 +125,11 @@ def load_library(build_if_missing=False):
     lib.ws_search_device.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, vp]
     lib.ws_enqueue_host.argtypes = [vp, P(_Params), P(_Image), P(_Image), vp, ci, ci]
     lib.ws_wait.argtypes = [vp]
+    cf = ctypes.c_float
+    lib.ws_remove_disparity_outliers.argtypes = [vp, vp, ci, ci, ci, ci, cf, cf]
+    lib.ws_convert_disparity_to_depth.argtypes = [vp, vp, ci, ci, ci, cf, cf, vp, ci]
+    lib.ws_back_project.argtypes = [vp, vp, ci, ci, ci, P(cf), P(_Image), vp, vp]
+    lib.ws_write_mesh_off.argtypes = [ctypes.c_char_p, vp, vp, ci, ci, cf]
     lib.ws_warp_nearest_host.argtypes = [vp, vp, ci, ci, ci, P(ctypes.c_double), vp, ci, ci, ci]
     lib.ws_warp_nearest_device.argtypes = [vp, vp, ci, ci, ci, P(ctypes.c_double), vp, ci, ci, ci, vp]
     lib.ws_timer_begin.argtypes = [vp, vp]
@@ -236,6 +242,30 @@ class WindowSearch:
         self._check(self._lib.ws_warp_nearest_host(self._h, a.ctypes.data, a.shape[1], a.shape[0], a.shape[1],
                                                    m, out.ctypes.data, out.shape[1], out.shape[0], out.shape[1]))
         return out
+
+    # -- consumers (Reconstruction side) ---------------------------------------------------
+    def remove_disparity_outliers(self, disparity, kernel_size, thr_front, thr_back):
+        m = np.array(disparity, dtype=np.float32, order="C")
+        self._check(self._lib.ws_remove_disparity_outliers(self._h, m.ctypes.data, m.shape[1], m.shape[0], m.shape[1],
+                                                           kernel_size, thr_front, thr_back))
+        return m
+
+    def convert_disparity_to_depth(self, disparity, focal_length, baseline):
+        d = np.ascontiguousarray(disparity, dtype=np.float32)
+        out = np.empty_like(d)
+        self._check(self._lib.ws_convert_disparity_to_depth(self._h, d.ctypes.data, d.shape[1], d.shape[0], d.shape[1],
+                                                            focal_length, baseline, out.ctypes.data, out.shape[1]))
+        return out
+
+    def back_project(self, depth, intrinsics, bgr):
+        z = np.ascontiguousarray(depth, dtype=np.float32)
+        img, hdr = _host_image(bgr)
+        k = (ctypes.c_float * 9)(*np.asarray(intrinsics, dtype=np.float32).reshape(9))
+        pos = np.empty(z.shape + (4,), dtype=np.float32)
+        col = np.empty(z.shape + (4,), dtype=np.uint8)
+        self._check(self._lib.ws_back_project(self._h, z.ctypes.data, z.shape[1], z.shape[0], z.shape[1], k,
+                                              ctypes.byref(hdr), pos.ctypes.data, col.ctypes.data))
+        return pos, col
 
     def timer_begin(self, stream=None):
         self._check(self._lib.ws_timer_begin(self._h, ctypes.c_void_p(stream or 0)))
@@ -353,6 +383,15 @@ def write_pfm(path, array):
     rc = load_library().ws_pfm_write(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], a.shape[1])
     if rc != 0:
         raise WsError(rc, "cannot write PFM %s" % path)
+
+
+def write_mesh_off(path, positions, colors, edge_threshold):
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    col = np.ascontiguousarray(colors, dtype=np.uint8)
+    h, w = pos.shape[:2]
+    rc = load_library().ws_write_mesh_off(os.fsencode(path), pos.ctypes.data, col.ctypes.data, w, h, edge_threshold)
+    if rc != 0:
+        raise WsError(rc, "cannot write mesh %s" % path)
 
 
 def read_calib(path):

@@ -35,7 +35,9 @@ def build(force=False, verbose=False):
     """Compile the shared library if it is missing or older than its sources."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=off: the few floating-point kernels (warp, depth, back-projection, smoothFactor)
+    # must round every product like the reference's x86-64 build does; the hot kernels are integer
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -561,6 +562,80 @@ int ws_warp_nearest_host(ws_context *ctx, const double *src, int src_w, int src_
     return WS_OK;
 }
 
+// ---- consumers of the map (src/Reconstruction/reconstruction.cpp) ----------------------
+
+int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int height, int stride, int kernel_size,
+                                 float thr_front, float thr_back)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (!map || width <= 0 || height <= 0 || stride < width || kernel_size < 1)
+        return fail(ctx, WS_ERR_ARG, "bad removeDisparityOutliers arguments");
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)width * height;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out64, n * 8)) != WS_OK) return rc;
+    float *dmap = static_cast<float *>(ctx->d_out.p);
+    WS_HIP(ctx, hipMemcpy2DAsync(dmap, (size_t)width * 4, map, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
+    WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
+    WS_HIP(ctx, hipMemcpy2DAsync(map, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
+    WS_HIP(ctx, hipStreamSynchronize(s));
+    return WS_OK;
+}
+
+static int depth_vertices_host(ws_context *ctx, const float *in, int width, int height, int stride, int input_is_depth,
+                               float focal, float baseline, const float *k, const ws_image *bgr, float *depth,
+                               int depth_stride, float *positions, uint8_t *colors)
+{
+    if (!ctx) return WS_ERR_ARG;
+    if (!in || width <= 0 || height <= 0 || stride < width) return fail(ctx, WS_ERR_ARG, "bad map");
+    if (positions && (!colors || !k || !bgr || !bgr->data || bgr->width != width || bgr->height != height ||
+                      bgr->stride < 3 * width))
+        return fail(ctx, WS_ERR_ARG, "back-projection needs K, a colour image of the map's size and both outputs");
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)width * height;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out64, n * 4 + n * 16 + n * 4)) != WS_OK) return rc;
+    if (positions && (rc = ensure(ctx, ctx->d_left, n * 3)) != WS_OK) return rc;
+    float *din = static_cast<float *>(ctx->d_out.p);
+    uint8_t *base = static_cast<uint8_t *>(ctx->d_out64.p);
+    float *dpos = reinterpret_cast<float *>(base);           // n * 16 bytes, 16-byte aligned
+    float *ddepth = reinterpret_cast<float *>(base + n * 16); // n * 4
+    uint8_t *dcol = base + n * 20;                            // n * 4
+    WS_HIP(ctx, hipMemcpy2DAsync(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
+    if (positions)
+        WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, (size_t)width * 3, bgr->data, bgr->stride, (size_t)width * 3, height, hipMemcpyHostToDevice, s));
+    WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
+                                      static_cast<const uint8_t *>(ctx->d_left.p), width * 3, depth ? ddepth : nullptr, width,
+                                      positions ? dpos : nullptr, positions ? dcol : nullptr, input_is_depth, s));
+    if (depth)
+        WS_HIP(ctx, hipMemcpy2DAsync(depth, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
+    if (positions) {
+        WS_HIP(ctx, hipMemcpyAsync(positions, dpos, n * 16, hipMemcpyDeviceToHost, s));
+        WS_HIP(ctx, hipMemcpyAsync(colors, dcol, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    WS_HIP(ctx, hipStreamSynchronize(s));
+    return WS_OK;
+}
+
+int ws_convert_disparity_to_depth(ws_context *ctx, const float *disp, int width, int height, int stride, float focal_length,
+                                  float baseline, float *depth, int depth_stride)
+{
+    if (!depth || depth_stride < width) return ctx ? fail(ctx, WS_ERR_ARG, "bad depth output") : WS_ERR_ARG;
+    return depth_vertices_host(ctx, disp, width, height, stride, 0, focal_length, baseline, nullptr, nullptr, depth,
+                               depth_stride, nullptr, nullptr);
+}
+
+int ws_back_project(ws_context *ctx, const float *depth, int width, int height, int stride, const float intrinsics[9],
+                    const ws_image *bgr, float *positions, uint8_t *colors)
+{
+    if (!positions || !colors) return ctx ? fail(ctx, WS_ERR_ARG, "null vertex output") : WS_ERR_ARG;
+    return depth_vertices_host(ctx, depth, width, height, stride, 1, 0.0f, 0.0f, intrinsics, bgr, nullptr, 0, positions, colors);
+}
+
 int ws_timer_begin(ws_context *ctx, void *stream)
 {
     if (!ctx) return WS_ERR_ARG;
@@ -681,6 +756,49 @@ static bool parse_cam(const char *line, float m[9])
     s = s.substr(6, s.size() - 7);
     std::replace(s.begin(), s.end(), ';', ' ');
     return sscanf(s.c_str(), "%f %f %f %f %f %f %f %f %f", m, m + 1, m + 2, m + 3, m + 4, m + 5, m + 6, m + 7, m + 8) == 9;
+}
+
+// WriteMesh (reconstruction.cpp:72-149) with CheckTriangularValidity (:46-69): COFF text, every
+// vertex written (invalid ones as "0 0 0"), two triangles per grid cell when all three corners are
+// valid and every edge is at most edge_threshold long.  Host only: file I/O bound.
+static bool mesh_triangle_ok(const float *pos, unsigned a, unsigned b, unsigned c, float thr)
+{
+    const float minf = -INFINITY;
+    if (pos[4 * a] == minf || pos[4 * b] == minf || pos[4 * c] == minf) return false;
+    auto len = [&](unsigned p, unsigned q) {
+        return sqrtf(powf(pos[4 * p] - pos[4 * q], 2) + powf(pos[4 * p + 1] - pos[4 * q + 1], 2) +
+                     powf(pos[4 * p + 2] - pos[4 * q + 2], 2));
+    };
+    return !(len(a, b) > thr || len(a, c) > thr || len(b, c) > thr);
+}
+
+int ws_write_mesh_off(const char *path, const float *positions, const uint8_t *colors, int width, int height,
+                      float edge_threshold)
+{
+    if (!path || !positions || !colors || width <= 0 || height <= 0) return WS_ERR_ARG;
+    std::vector<unsigned> tri;
+    const unsigned w = (unsigned)width, h = (unsigned)height;
+    for (unsigned y = 0; y + 1 < h; ++y)
+        for (unsigned x = 0; x + 1 < w; ++x) {
+            const unsigned i00 = y * w + x, i10 = (y + 1) * w + x, i01 = y * w + x + 1, i11 = (y + 1) * w + x + 1;
+            if (mesh_triangle_ok(positions, i00, i10, i01, edge_threshold)) { tri.push_back(i00); tri.push_back(i10); tri.push_back(i01); }
+            if (mesh_triangle_ok(positions, i10, i11, i01, edge_threshold)) { tri.push_back(i10); tri.push_back(i11); tri.push_back(i01); }
+        }
+    std::ofstream out(path);
+    if (!out.is_open()) return WS_ERR_IO;
+    out << "COFF" << std::endl;
+    out << (size_t)w * h << " " << tri.size() / 3 << " 0" << std::endl;
+    const float minf = -INFINITY;
+    for (size_t n = 0; n < (size_t)w * h; ++n) {
+        if (positions[4 * n] == minf) out << "0 0 0 ";
+        else out << positions[4 * n] << " " << positions[4 * n + 1] << " " << positions[4 * n + 2] << " ";
+        out << (unsigned)colors[4 * n] << " " << (unsigned)colors[4 * n + 1] << " " << (unsigned)colors[4 * n + 2] << " "
+            << (unsigned)colors[4 * n + 3] << std::endl;
+    }
+    for (size_t n = 0; n < tri.size() / 3; ++n)
+        out << "3 " << tri[3 * n] << " " << tri[3 * n + 1] << " " << tri[3 * n + 2] << std::endl;
+    out.close();
+    return out.fail() ? WS_ERR_IO : WS_OK;
 }
 
 int ws_calib_read(const char *path, ws_calib *out)

@@ -88,6 +88,13 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
 // nearest-neighbour perspective warp of a float map; minv maps destination -> source pixels
 hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
                        const double minv[9], hipStream_t s);
+// removeDisparityOutliers (reconstruction.cpp:5-18); scratch = w*h doubles
+hipError_t launch_outliers(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, double *scratch,
+                           hipStream_t s);
+// convertDisparityToDepth + back-projection (reconstruction.cpp:30-43, :152-196); depth / pos+col may be null
+hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float focal, float baseline, const float k[9],
+                                 const uint8_t *bgr, int bstride, float *depth, int zp, float *pos, uint8_t *col,
+                                 int input_is_depth, hipStream_t s);
 // float32 -> float64 widening for CV_64F outputs
 hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
                         hipStream_t s);

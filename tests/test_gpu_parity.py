@@ -173,6 +173,30 @@ def test_warp_back_to_the_original_frame(wslib, gpu_ctx, oracle):
         assert (got != 0).any()
 
 
+def test_reconstruction_consumers(wslib, gpu_ctx, oracle, tmp_path):
+    """The map's consumers (reconstruction.cpp:5-43, :152-196) as main.cpp:50-64 chains them:
+    8-bit disparity -> removeDisparityOutliers(500, 1.5, 0.8) -> depth -> vertices -> OFF mesh."""
+    left, right, gt = make_pair(300, 220, 64, seed=17)
+    disp8 = np.clip(gt, 0, 255).astype(np.float32)            # what readGrayscaleImageAsDisparityMap yields
+    disp8[50:60, 70:90] = 0
+    disp8[100, 100] = 250
+    for k in (500, 31, 4):
+        got = gpu_ctx.remove_disparity_outliers(disp8, k, 1.5, 0.8)
+        assert np.array_equal(got, oracle.remove_disparity_outliers(disp8, k, 1.5, 0.8)), k
+    filt = gpu_ctx.remove_disparity_outliers(disp8, 500, 1.5, 0.8)
+    depth = gpu_ctx.convert_disparity_to_depth(filt, 3000.0, 1.0)
+    assert np.array_equal(depth, oracle.convert_disparity_to_depth(filt, 3000.0, 1.0))
+    zero = gpu_ctx.convert_disparity_to_depth(disp8, 3000.0, 1.0)
+    assert np.isneginf(zero[55, 75])
+    K = np.array([[3000, 0, 150], [0, 3000, 110], [0, 0, 1]], dtype=np.float32)
+    pos, col = gpu_ctx.back_project(zero, K, right)
+    wpos, wcol = oracle.back_project(zero, K, right)
+    assert np.array_equal(pos, wpos) and np.array_equal(col, wcol)
+    path = str(tmp_path / "mesh.off")
+    wslib.write_mesh_off(path, pos[40:70, 60:100], col[40:70, 60:100], 1.0)
+    assert open(path).read() == oracle.mesh_off_text(pos[40:70, 60:100], col[40:70, 60:100], 1.0)
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:

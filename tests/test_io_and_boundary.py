@@ -130,3 +130,18 @@ def test_cxx_facade_compiles_and_links(wslib, tmp_path):
            "-Wl,-rpath," + os.path.join(ROOT, "stereo_reconstruction_amd")]
     subprocess.check_call(cmd)
     assert os.path.exists(exe)
+
+
+def test_mesh_writer_matches_the_restatement(wslib, oracle, tmp_path):
+    """WriteMesh (reconstruction.cpp:72-149) is host-only: text identical to the Python restatement."""
+    rng = np.random.default_rng(4)
+    h, w = 9, 13
+    z = rng.uniform(20, 22, size=(h, w)).astype(np.float32)
+    z[2, 3] = -np.inf
+    bgr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    pos, col = oracle.back_project(z, [[100, 0, 6], [0, 100, 4], [0, 0, 1]], bgr)
+    path = str(tmp_path / "m.off")
+    for thr in (0.5, 5.0):
+        wslib.write_mesh_off(path, pos, col, thr)
+        assert open(path).read() == oracle.mesh_off_text(pos, col, thr)
+    assert open(path).read().startswith("COFF\n117 ")

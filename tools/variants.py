@@ -15,7 +15,7 @@ def build(specs):
         x, nd, maxt = parts[:3]
         extra = parts[3:]
         out = os.path.join(VDIR, "libws_%s.so" % spec.replace(",", "_"))
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-DWS_X=" + x, "-DWS_ND=" + nd, "-DWS_MAXT=" + maxt] + ["-D" + e for e in extra] + [
                "-Rpass-analysis=kernel-resource-usage", "-o", out,
                os.path.join(CSRC, "ws_kernels.hip"), os.path.join(CSRC, "ws_capi.cpp")]
