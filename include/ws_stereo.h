@@ -210,6 +210,13 @@ int ws_pfm_read(const char *path, float **data, int *width, int *height);
 int ws_pfm_write(const char *path, const float *data, int width, int height, int stride);
 void ws_free(void *p);
 /*
+ * Binary PPM ("P6") <-> BGR rows: stands in for cv::imread(IMREAD_COLOR) / cv::imwrite of the
+ * reference's PNG pairs (data_loader.cpp:71-72); no PNG codec is linked.  ws_ppm_read allocates
+ * *bgr with malloc (release with ws_free).
+ */
+int ws_ppm_read(const char *path, uint8_t **bgr, int *width, int *height);
+int ws_ppm_write(const char *path, const uint8_t *bgr, int width, int height, int stride);
+/*
  * calib.txt: cam0 / cam1 as the reference parses them (data_loader.cpp:141-164), row-major
  * 3x3 each, plus the keys it leaves unread (ndisp, doffs, baseline, width, height; -1 if absent).
  */

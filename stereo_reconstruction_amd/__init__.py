@@ -23,7 +23,7 @@ import numpy as np
 from . import build as _build
 
 __all__ = ["WindowSearch", "BlockSearch", "LinearSearch", "WsError", "load_library",
-           "read_pfm", "write_pfm", "read_calib", "evaldisp", "VIEW_LEFT", "VIEW_RIGHT",
+           "read_pfm", "write_pfm", "read_ppm", "write_ppm", "write_mesh_off", "read_calib", "evaldisp", "VIEW_LEFT", "VIEW_RIGHT",
            "VIEW_LINEAR", "COST_SSD", "COST_SAD"]
 
 VIEW_LEFT, VIEW_RIGHT, VIEW_LINEAR = 0, 1, 2
@@ -41,7 +41,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
            "ws_last_launch_info", "ws_set_tuning",
-           "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_calib_read", "ws_evaldisp"]
+           "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
 class WsError(RuntimeError):
@@ -140,6 +140,8 @@ def load_library(build_if_missing=False):
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
     lib.ws_pfm_write.argtypes = [ctypes.c_char_p, vp, ci, ci, ci]
+    lib.ws_ppm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_uint8)), P(ci), P(ci)]
+    lib.ws_ppm_write.argtypes = [ctypes.c_char_p, vp, ci, ci, ci]
     lib.ws_free.argtypes = [vp]
     lib.ws_free.restype = None
     lib.ws_calib_read.argtypes = [ctypes.c_char_p, P(_Calib)]
@@ -392,6 +394,27 @@ def write_mesh_off(path, positions, colors, edge_threshold):
     rc = load_library().ws_write_mesh_off(os.fsencode(path), pos.ctypes.data, col.ctypes.data, w, h, edge_threshold)
     if rc != 0:
         raise WsError(rc, "cannot write mesh %s" % path)
+
+
+def read_ppm(path):
+    """P6 file -> H x W x 3 uint8 in BGR order (what cv::imread(IMREAD_COLOR) would give)."""
+    lib = load_library()
+    data = ctypes.POINTER(ctypes.c_uint8)()
+    w, h = ctypes.c_int(), ctypes.c_int()
+    rc = lib.ws_ppm_read(os.fsencode(path), ctypes.byref(data), ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        raise WsError(rc, "cannot read PPM %s" % path)
+    try:
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.ws_free(data)
+
+
+def write_ppm(path, bgr):
+    a = np.ascontiguousarray(bgr, dtype=np.uint8)
+    rc = load_library().ws_ppm_write(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], a.strides[0])
+    if rc != 0:
+        raise WsError(rc, "cannot write PPM %s" % path)
 
 
 def read_calib(path):

@@ -746,6 +746,52 @@ int ws_pfm_write(const char *path, const float *data, int width, int height, int
     return fclose(f) == 0 ? WS_OK : WS_ERR_IO;
 }
 
+// Binary PPM ("P6", maxval 255) <-> BGR rows, standing in for cv::imread(IMREAD_COLOR) / imwrite
+// of the reference's PNGs (data_loader.cpp:71-72): no PNG decoder is linked here.
+int ws_ppm_read(const char *path, uint8_t **bgr, int *width, int *height)
+{
+    if (!path || !bgr || !width || !height) return WS_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return WS_ERR_IO;
+    char tag[3] = {0};
+    int vals[3], n = 0;
+    if (fread(tag, 1, 2, f) != 2 || tag[0] != 'P' || tag[1] != '6') { fclose(f); return WS_ERR_IO; }
+    while (n < 3) { // width, height, maxval with '#' comments allowed between them
+        int c = fgetc(f);
+        if (c == EOF) { fclose(f); return WS_ERR_IO; }
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r') continue;
+        ungetc(c, f);
+        if (fscanf(f, "%d", &vals[n]) != 1) { fclose(f); return WS_ERR_IO; }
+        ++n;
+    }
+    fgetc(f); // the single whitespace byte before the pixels
+    const int w = vals[0], h = vals[1];
+    if (w <= 0 || h <= 0 || vals[2] != 255) { fclose(f); return WS_ERR_IO; }
+    uint8_t *buf = static_cast<uint8_t *>(malloc((size_t)w * h * 3));
+    if (!buf) { fclose(f); return WS_ERR_NOMEM; }
+    if (fread(buf, 3, (size_t)w * h, f) != (size_t)w * h) { free(buf); fclose(f); return WS_ERR_IO; }
+    fclose(f);
+    for (size_t i = 0; i < (size_t)w * h; ++i) std::swap(buf[3 * i], buf[3 * i + 2]); // RGB -> BGR
+    *bgr = buf; *width = w; *height = h;
+    return WS_OK;
+}
+
+int ws_ppm_write(const char *path, const uint8_t *bgr, int width, int height, int stride)
+{
+    if (!path || !bgr || width <= 0 || height <= 0 || stride < 3 * width) return WS_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return WS_ERR_IO;
+    fprintf(f, "P6\n%d %d\n255\n", width, height);
+    std::vector<uint8_t> row((size_t)width * 3);
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *p = bgr + (size_t)y * stride;
+        for (int x = 0; x < width; ++x) { row[3 * x] = p[3 * x + 2]; row[3 * x + 1] = p[3 * x + 1]; row[3 * x + 2] = p[3 * x]; }
+        if (fwrite(row.data(), 1, row.size(), f) != row.size()) { fclose(f); return WS_ERR_IO; }
+    }
+    return fclose(f) == 0 ? WS_OK : WS_ERR_IO;
+}
+
 static bool parse_cam(const char *line, float m[9])
 {
     // "cam0=[fx 0 cx; 0 fy cy; 0 0 1]": drop 6 leading characters and the closing bracket,

@@ -241,6 +241,56 @@ private:
     MatF64 disparityMapLeft, disparityMapRight;
 };
 
+// A CV_32FC1 map owned by value (what main.cpp:50-64 hands from stage to stage).
+class MatF32 {
+public:
+    MatF32() = default;
+    MatF32(int rows, int cols) : rows(rows), cols(cols), buf_(static_cast<size_t>(rows) * cols, 0.0f) {}
+    int rows = 0, cols = 0;
+    float &at(int y, int x) { return buf_[static_cast<size_t>(y) * cols + x]; }
+    float at(int y, int x) const { return buf_[static_cast<size_t>(y) * cols + x]; }
+    float *ptr() { return buf_.data(); }
+    const float *ptr() const { return buf_.data(); }
+
+private:
+    std::vector<float> buf_;
+};
+
+// Reconstruction/reconstruction.h:26-33 with the same names and argument order.
+inline void removeDisparityOutliers(MatF32 &disparityMap, int kernelSize, float thrFront, float thrBack,
+                                    Device &device = Device::shared())
+{
+    const int rc = ws_remove_disparity_outliers(device.get(), disparityMap.ptr(), disparityMap.cols, disparityMap.rows,
+                                                disparityMap.cols, kernelSize, thrFront, thrBack);
+    if (rc != WS_OK) throw Error(rc, ws_last_error(device.get()));
+}
+
+inline MatF32 convertDisparityToDepth(const MatF32 &dispImage, float focalLength, float baseline,
+                                      Device &device = Device::shared())
+{
+    MatF32 depth(dispImage.rows, dispImage.cols);
+    const int rc = ws_convert_disparity_to_depth(device.get(), dispImage.ptr(), dispImage.cols, dispImage.rows,
+                                                 dispImage.cols, focalLength, baseline, depth.ptr(), depth.cols);
+    if (rc != WS_OK) throw Error(rc, ws_last_error(device.get()));
+    return depth;
+}
+
+// reconstruction(bgrImage, depthValues, intrinsics, thrMesh) (reconstruction.cpp:152-208); the
+// reference's hard-coded output path becomes an argument.
+inline void reconstruction(const Image8UC3 &bgrImage, const MatF32 &depthValues, const float intrinsics[9],
+                           float thrMesh, const std::string &meshPath, Device &device = Device::shared())
+{
+    const size_t n = static_cast<size_t>(depthValues.rows) * depthValues.cols;
+    std::vector<float> positions(4 * n);
+    std::vector<uint8_t> colors(4 * n);
+    const ws_image img = detail::to_c(bgrImage);
+    int rc = ws_back_project(device.get(), depthValues.ptr(), depthValues.cols, depthValues.rows, depthValues.cols,
+                             intrinsics, &img, positions.data(), colors.data());
+    if (rc != WS_OK) throw Error(rc, ws_last_error(device.get()));
+    rc = ws_write_mesh_off(meshPath.c_str(), positions.data(), colors.data(), depthValues.cols, depthValues.rows, thrMesh);
+    if (rc != WS_OK) throw Error(rc, "Failed to write mesh! Check file path!");
+}
+
 #ifdef WSAMD_WITH_OPENCV
 inline Image8UC3 view(const cv::Mat &m)
 {

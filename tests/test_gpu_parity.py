@@ -308,6 +308,31 @@ def test_cxx_facade_runs_the_reference_call_surface(wslib, oracle, tmp_path):
     assert rc == 12
 
 
+def test_example_pipeline_equals_the_python_chain(wslib, gpu_ctx, oracle, tmp_path):
+    """examples/pipeline_main.cpp (the reference's main.cpp:13-66 on a rectified pair) end to end."""
+    exe = str(tmp_path / "pipeline_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, "-o", exe, os.path.join(ROOT, "examples", "pipeline_main.cpp"),
+                           "-L", os.path.join(ROOT, "stereo_reconstruction_amd"), "-lws_stereo",
+                           "-Wl,-rpath," + os.path.join(ROOT, "stereo_reconstruction_amd")])
+    left, right, _ = make_pair(240, 140, 60, seed=23)
+    wslib.write_ppm(str(tmp_path / "im0.ppm"), left)
+    wslib.write_ppm(str(tmp_path / "im1.ppm"), right)
+    prefix = str(tmp_path / "out")
+    subprocess.check_call([exe, str(tmp_path / "im0.ppm"), str(tmp_path / "im1.ppm"),
+                           os.path.join(ROOT, "tests", "golden", "teddy_calib.txt"), prefix])
+    disp = oracle.block_right(left, right, 17, 0, 200, smooth=0.9)
+    d8 = np.clip(np.rint(disp), 0, 255).astype(np.float32)
+    assert np.array_equal(wslib.read_pfm(prefix + "_disparity.pfm"), d8)
+    filt = oracle.remove_disparity_outliers(d8, 500, 1.5, 0.8)
+    depth = oracle.convert_disparity_to_depth(filt, 3000.0, 1.0)
+    K = wslib.read_calib(os.path.join(ROOT, "tests", "golden", "teddy_calib.txt"))["cam1"]
+    pos, col = oracle.back_project(depth, K, right)
+    head = open(prefix + "_mesh.off").read().split("\n")[:2 + 240 * 3]
+    want = oracle.mesh_off_text(pos[:4], col[:4], 1.0).split("\n")
+    assert head[0] == "COFF" and head[1].split()[0] == str(240 * 140)
+    assert head[2:2 + 240 * 3] == want[2:2 + 240 * 3]        # the first three rows of vertices
+
+
 def test_teddy_quarter_bad2_same_as_cpu(wslib, gpu_ctx, oracle):
     """bad-2.0 (evaldisp, utils.cpp:123-168) of the device map equals that of the CPU map."""
     g = load_golden("teddy_quarter")
