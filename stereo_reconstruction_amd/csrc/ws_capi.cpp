@@ -46,7 +46,7 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, sel, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, sel, sel_planes, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
@@ -193,7 +193,9 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
-    WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch, s));
+    if ((rc = ensure(ctx, ctx->sel_planes, smooth_planes_bytes(R->width, R->height))) != WS_OK) return rc;
+    WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch,
+                              static_cast<unsigned long long *>(ctx->sel_planes.p), s));
     if (p->subpixel) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
     return WS_OK;
 }
@@ -334,7 +336,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->sel, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);

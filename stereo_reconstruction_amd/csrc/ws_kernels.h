@@ -84,7 +84,10 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
-hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st);
+// bytes of the bit-plane scratch launch_smooth wants for a w x h map
+size_t smooth_planes_bytes(int w, int h);
+hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
+                         hipStream_t st);
 // nearest-neighbour perspective warp of a float map; minv maps destination -> source pixels
 hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
                        const double minv[9], hipStream_t s);

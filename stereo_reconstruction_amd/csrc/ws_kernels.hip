@@ -1228,15 +1228,127 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, 
     }
 }
 
+// ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
+// There c0 * s^k does not grow with k, so t_0 >= t_1 >= t_2 and a pixel is one of: always 0
+// ("generate"), never 0 ("kill"), or 0 exactly when its left neighbour is ("propagate") -- a
+// carry chain.  With the codes packed into bit planes (64 columns per word) one lane resolves 64
+// columns with a single 64-bit addition (A = g|p, B = g: the carries of A+B are the chain), and
+// the carries between the lanes' words come from the same addition on two ballot masks in the
+// scalar unit.  ~40 bit operations per row for the whole image width.
+__global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__restrict__ sel, int sel_pitch, int w,
+                                                               unsigned long long *__restrict__ planes, int nwp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const uint32_t c = x < w ? sel[(size_t)y * sel_pitch + x] : kSelFixed; // beyond the row: fixed, non-zero
+    const bool fixed = c & kSelFixed;
+    const unsigned long long t0 = __ballot(!fixed && (c & 1)), t1 = __ballot(!fixed && (c & 2)),
+                             t2 = __ballot(!fixed && (c & 4)), fx = __ballot(fixed),
+                             zf = __ballot(fixed && (c & kSelZero));
+    if ((threadIdx.x & 63) == 0 && (x >> 6) < nwp) {
+        unsigned long long *row = planes + (size_t)y * 5 * nwp + (x >> 6);
+        row[0] = t0; row[nwp] = t1; row[2 * nwp] = t2; row[3 * nwp] = fx; row[4 * nwp] = zf;
+    }
+}
+
+__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const unsigned long long *__restrict__ planes, int nwp,
+                                                                    int rows, unsigned long long *__restrict__ zplane,
+                                                                    int chunk_rows)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    extern __shared__ uint4 ws_smem4[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
+    const int lane = threadIdx.x;
+    const int row_bytes = 5 * nwp * 8; // nwp is even: a multiple of 16 bytes
+    const int chunk_bytes = chunk_rows * row_bytes;
+    const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    const uint8_t *src0 = reinterpret_cast<const uint8_t *>(planes);
+    for (int o = lane * 16; o < chunk_bytes; o += 1024)
+        __builtin_amdgcn_global_load_lds((glb_void *)(src0 + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
+    unsigned long long zprev = 0;
+    const bool active = lane < nwp;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t *cur = lds + (c & 1) * chunk_bytes;
+        if (c + 1 < nchunks) {
+            const uint8_t *src = src0 + (size_t)(c + 1) * chunk_bytes;
+            uint8_t *dst = lds + ((c + 1) & 1) * chunk_bytes;
+            for (int o = lane * 16; o < chunk_bytes; o += 1024)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
+        }
+        const int y_end = min((c + 1) * chunk_rows, rows);
+        for (int y = c * chunk_rows; y < y_end; ++y) {
+            const unsigned long long *row = reinterpret_cast<const unsigned long long *>(cur + (size_t)(y - c * chunk_rows) * row_bytes);
+            unsigned long long g = 0, p = 0;
+            if (active) {
+                const unsigned long long t0 = row[lane], t1 = row[nwp + lane], t2 = row[2 * nwp + lane],
+                                         fx = row[3 * nwp + lane], zf = row[4 * nwp + lane];
+                // zero when the left neighbour is not / is zero, given the upper neighbour's flag
+                unsigned long long n0 = ~((t0 & ~zprev) | (t1 & zprev)), n1 = ~((t1 & ~zprev) | (t2 & zprev));
+                n0 = (n0 & ~fx) | zf;
+                n1 = (n1 & ~fx) | zf;
+                g = n0 & n1;
+                p = n1 & ~n0;
+            }
+            const unsigned long long A = g | p, B = g, S0 = A + B;
+            const bool cout0 = S0 < A, cout1 = cout0 || S0 == ~0ull;
+            // carries between the lanes' words: the same adder on the ballots (scalar unit)
+            const unsigned long long gw = __ballot(cout0), pw = __ballot(cout1 && !cout0);
+            const unsigned long long aw = gw | pw, sw = aw + gw, cw = sw ^ aw ^ gw; // bit l = carry into lane l
+            const unsigned long long cin = (cw >> lane) & 1ull; // column 0 of the row: no left neighbour
+            const unsigned long long S = S0 + cin;
+            const unsigned long long carries = S ^ A ^ B; // bit k = carry into column k
+            const unsigned long long cout = cin ? (unsigned long long)cout1 : (unsigned long long)cout0;
+            const unsigned long long z = (carries >> 1) | (cout << 63);
+            if (active) zplane[(size_t)y * nwp + lane] = z;
+            zprev = z;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_smooth_apply_kernel(float *out, int out_pitch, int w, int rows,
+                                                              const uint8_t *__restrict__ sel, int sel_pitch,
+                                                              const unsigned long long *__restrict__ zplane, int nwp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= rows) return;
+    if (sel[(size_t)y * sel_pitch + x] & kSelFixed) return;
+    if ((zplane[(size_t)y * nwp + (x >> 6)] >> (x & 63)) & 1ull) out[(size_t)y * out_pitch + x] = 0.0f;
+}
+
 int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
 
-hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, hipStream_t st)
+size_t smooth_planes_bytes(int w, int h)
+{
+    const int nwp = round_up(ceil_div(w, 64), 2);
+    return (size_t)(h + 64) * 6 * nwp * 8; // 5 code planes + the resolved plane
+}
+
+hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
+                         hipStream_t st)
 {
     dim3 grid(ceil_div(g.w2, 256), g.h2);
     hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int rows = std::min(g.h1, g.h2);
+    const int nwords = ceil_div(g.w2, 64);
+    if (s >= 0.0 && s <= 1.0 && nwords <= 64 && planes) {
+        const int nwp = round_up(nwords, 2);
+        unsigned long long *zplane = planes + (size_t)(g.h2 + 64) * 5 * nwp;
+        hipLaunchKernelGGL(ws_smooth_planes_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, sel, sel_pitch,
+                           g.w2, planes, nwp);
+        int chunk = 24576 / (5 * nwp * 8);
+        if (chunk > 64) chunk = 64;
+        if (chunk < 1) chunk = 1;
+        hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel, dim3(1), dim3(64), (size_t)2 * chunk * 5 * nwp * 8, st, planes,
+                           nwp, rows, zplane, chunk);
+        hipLaunchKernelGGL(ws_smooth_apply_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch,
+                           g.w2, rows, sel, sel_pitch, zplane, nwp);
+        return hipGetLastError();
+    }
     const int per = ceil_div(g.w2, 64);
     // rows per LDS chunk: two chunks in at most 64 KB, a multiple of 16 rows (whole 1 KB DMA pieces)
     int chunk = (32768 / sel_pitch) / 16 * 16;
