@@ -197,6 +197,45 @@ def test_reconstruction_consumers(wslib, gpu_ctx, oracle, tmp_path):
     assert open(path).read() == oracle.mesh_off_text(pos[40:70, 60:100], col[40:70, 60:100], 1.0)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WS_FUZZ_CASES", "48"))))
+def test_randomised_differential(wslib, gpu_ctx, oracle, seed):
+    """Random shapes / windows / ranges / views against the oracle: tile edges, D not a multiple
+    of the chunk, D larger than the image, unequal sizes, black patches, few grey levels."""
+    rng = np.random.default_rng(1000 + seed)
+    w1, h1 = int(rng.integers(20, 420)), int(rng.integers(12, 90))
+    same = rng.random() < 0.5
+    w2 = w1 if same else max(8, w1 + int(rng.integers(-40, 41)))
+    h2 = h1 if same else max(6, h1 + int(rng.integers(-6, 1)))      # h1 >= h2 keeps the right view legal
+    levels = int(rng.choice([256, 256, 4, 2]))
+    if levels == 256:
+        left = rng.integers(0, 256, size=(h1, w1, 3), dtype=np.uint8)
+        right = rng.integers(0, 256, size=(h2, w2, 3), dtype=np.uint8)
+        d0 = int(rng.integers(0, 30))
+        n = min(w1 - d0, w2)
+        if n > 0:
+            right[:min(h1, h2), :n] = left[:min(h1, h2), d0:d0 + n]   # something to find
+    else:
+        left = (rng.integers(0, levels, size=(h1, w1, 3)) * (255 // (levels - 1))).astype(np.uint8)
+        right = (rng.integers(0, levels, size=(h2, w2, 3)) * (255 // (levels - 1))).astype(np.uint8)
+    y, x = int(rng.integers(0, h1)), int(rng.integers(0, w1))
+    left[y:y + 3, x:x + 9] = 0
+    y, x = int(rng.integers(0, h2)), int(rng.integers(0, w2))
+    right[y:y + 2, x:x + 5] = 0
+    view = "left" if rng.random() < 0.5 else "right"
+    bs = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 19] if view == "left" else [2, 3, 5, 6, 7, 9, 12, 13, 17, 21]))
+    maxd = int(rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 100, 200, 300, 513]))
+    mind = int(rng.choice([0, 0, 1, 5])) if view == "right" else 0
+    cost = "ssd" if rng.random() < 0.5 else "sad"
+    smooth = float(rng.choice([1.0, 1.0, 0.9, 0.3])) if view == "right" else 1.0
+    b = wslib.BlockSearch(left, right, bs, mind, maxd, cost=cost, context=gpu_ctx)
+    if view == "left":
+        got, want = b.computeDisparityMapLeft(1.0), oracle.block_left(left, right, bs, mind, maxd, cost=cost, threads=8)
+    else:
+        got = b.computeDisparityMapRight(smooth)
+        want = oracle.block_right(left, right, bs, mind, maxd, smooth=smooth, cost=cost, threads=8)
+    assert np.array_equal(got, want), (view, bs, mind, maxd, cost, smooth, left.shape, right.shape, levels)
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
