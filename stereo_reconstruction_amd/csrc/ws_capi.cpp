@@ -46,7 +46,7 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, sel, sel_planes, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, keys, sel, sel_planes, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
@@ -238,7 +238,9 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
                                 ib->height, ib->stride, pb, c.mirror, march_centred(c), s));
         if (c.ssd) WS_HIP(ctx, launch_bias(c, m, pb, pbi, s));
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
-        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, s));
+        const int keys_pitch = (c.wa + 15) & ~15;
+        if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
+        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, ctx->keys.p, keys_pitch, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;
@@ -336,7 +338,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);
@@ -379,6 +381,7 @@ int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int
         out->interior_x0 = c.mirror ? c.wa - c.ox1 : c.ox0;
         out->interior_x1 = c.mirror ? c.wa - c.ox0 : c.ox1;
         out->interior_y0 = c.oy0; out->interior_y1 = c.oy1;
+        out->passes = m.passes;
     }
     return WS_OK;
 }

@@ -39,7 +39,8 @@ struct Plane {
 
 struct MarchLaunch {
     int x_per_thread, nd_per_thread; // X, ND template choice
-    int nxr, nch;                    // x-runs per tile, d-chunks per tile
+    int nxr, nch;                    // x-runs per tile, d-chunks per tile (and pass)
+    int passes;                      // d-group passes (1 unless the disparity range is very wide)
     int threads;                     // workgroup size
     int tiles, strips, strip_rows;
     size_t lds_bytes;
@@ -60,8 +61,9 @@ hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane
                        const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
                        int centred, hipStream_t s);
 hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s);
+// keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, hipStream_t s);
+                        float *out, int out_pitch, void *keys, int keys_pitch, hipStream_t s);
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 
 // Brute-force kernels on the original 8-bit images (original coordinates, literal rules).

@@ -30,6 +30,7 @@
 #include "ws_kernels.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -210,6 +211,10 @@ struct MarchArgs {
     int nxr, nch;
     int wx0, wy0, boff;
     int d_lo, d_hi, b_lo, b_hi;
+    int d_first;   // first disparity of chunk 0 in THIS launch (d_lo + pass * chunks * ND)
+    int pass_mode; // 0 = the only pass, 1 = first, 2 = middle, 3 = last of several d-group passes
+    void *keys;    // several passes: plane of the best keys so far (slot_t per pixel)
+    int keys_pitch;
     int ox0, ox1, oy0, oy1;
     int strip_rows, tiles, strips;
     int prefer_large, mirror, fallback_neg;
@@ -357,7 +362,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int ye = min(ys + g.strip_rows, g.oy1);
     if (ys >= ye) return; // uniform per workgroup
 
-    const int dhi_t = g.d_lo + dt - 1;
+    const int dhi_t = g.d_first + dt - 1;
     const uint32_t *gA = g.A + (tile_x0 + g.wx0 + g.pad_a);
     const uint32_t *gB = g.B + (tile_x0 + g.wx0 + g.boff - dhi_t + g.pad_b);
     const uint32_t *gBi = SSD ? reinterpret_cast<const uint32_t *>(g.bias) + (tile_x0 + g.boff - dhi_t + g.pad_bi) : nullptr;
@@ -369,7 +374,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     // run starts, in quads of region 0: A at column X*r, B / bias at X*r + ND*(nch-1-c)
     const int ia = 4 * r;
     const int ib = 4 * (r + (ND / X) * (g.nch - 1 - (worker ? c : 0)));
-    const int d0 = g.d_lo + c * ND; // first disparity of this thread's chunk
+    const int d0 = g.d_first + c * ND; // first disparity of this thread's chunk
     const int shift = SSD ? LT + 1 : g.tag_bits;
     // global tie tag of local tag jt is ctag + jt (SSD merge)
     const int ctag = g.prefer_large ? g.d_hi - d0 - (ND - 1) : d0 - g.d_lo;
@@ -419,9 +424,19 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             const uint32_t *rowA = ringA + out_slot * a_w;
             for (int k = tid; k < tx; k += NT) {
                 const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r]
-                const slot_t key = sl[si];
+                slot_t key = sl[si];
                 sl[si] = kEmpty;
                 const int x = tile_x0 + k;
+                if (x < g.ox1 && g.pass_mode != 0) {
+                    // disparity ranges too wide for one tile run as several d-group passes that
+                    // meet in a plane of keys (same keys, same ordering: min is the merge)
+                    slot_t *kp = static_cast<slot_t *>(g.keys) + (size_t)y * g.keys_pitch + x;
+                    if (g.pass_mode != 1) key = min(key, *kp);
+                    if (g.pass_mode != 3) {
+                        *kp = key;
+                        continue;
+                    }
+                }
                 if (x < g.ox1) {
                     const int xo = g.mirror ? g.wa - 1 - x : x;
                     float val;
@@ -502,6 +517,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 #define WS_MAXT 512
 #endif
 constexpr int kX = WS_X, kND = WS_ND, kMaxT = WS_MAXT; // build-time tuning (tools/variants.py)
+constexpr int kMaxChunks = 64; // at most 512 disparities per tile and pass (tools/time_calls.py)
 constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1536)
 
 typedef void (*MarchFn)(const MarchArgs);
@@ -543,7 +559,6 @@ bool march_supported(const Canon &c)
     if (c.ox1 <= c.ox0 || c.oy1 <= c.oy0) return false;
     const int dcount = c.d_hi - c.d_lo + 1;
     if (dcount < 1) return false;
-    if (ceil_div(dcount, kND) > kMaxT / kMinXRuns) return false;
     // keys must stay inside (-2^28, 2^28)
     //   SSD: (2 * cross sum) << log2(ND)        SAD: window sum << tag bits
     const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * (march_centred(c) ? 128 * 128 : 255 * 255) * kND
@@ -561,7 +576,17 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     m.max_threads = kMaxT;
     const int dcount = c.d_hi - c.d_lo + 1;
     const int out_w = c.ox1 - c.ox0, out_h = c.oy1 - c.oy0;
-    m.nch = ceil_div(dcount, kND);
+    // d-chunks per tile.  One tile holds at most kMaxChunks chunks (wider disparity ranges would
+    // leave too few columns per tile); beyond that the range is cut into equal d-group passes that
+    // meet in a plane of keys.
+    const int nch_total = ceil_div(dcount, kND);
+    static const int max_chunks = [] {
+        const char *e = getenv("WS_MAX_CHUNKS"); // development knob
+        const int v = e ? atoi(e) : 0;
+        return v >= 8 && v <= kMaxT / kMinXRuns ? v : kMaxChunks;
+    }();
+    m.passes = ceil_div(nch_total, max_chunks);
+    m.nch = ceil_div(nch_total, m.passes);
     if (m.nch < 8) m.nch = 8;
     int maxt = kMaxT;
     if (tune_threads >= 64 && tune_threads < kMaxT) maxt = tune_threads / 64 * 64;
@@ -616,8 +641,8 @@ static int aligned_pad(int base)
 void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias)
 {
     const int tx = m.nxr * m.x_per_thread, dt = m.nch * m.nd_per_thread;
-    const int dhi_t = c.d_lo + dt - 1;
-    const int n_a = tx + c.ww - 1, n_b = tx + c.ww + dt - 2, n_bi = tx + dt - 1;
+    const int dhi_t = c.d_lo + m.passes * dt - 1; // the last pass reaches furthest to the left
+    const int n_a = tx + c.ww - 1, n_b = tx + c.ww + m.passes * dt - 2, n_bi = tx + m.passes * dt - 1;
     // first column each tile row copy starts at (tile 0); tiles advance by tx (a multiple of 8)
     const int base_a = c.ox0 + c.wx0;
     const int base_b = c.ox0 + c.wx0 + c.boff - dhi_t;
@@ -663,7 +688,7 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &)
 }
 
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, hipStream_t s)
+                        float *out, int out_pitch, void *keys, int keys_pitch, hipStream_t s)
 {
     const MarchEntry *e = find_march(c);
     if (!e) return hipErrorInvalidValue;
@@ -707,7 +732,13 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
         if (err != hipSuccess) return err;
     }
     dim3 grid(round_up(m.tiles * m.strips, 8));
-    hipLaunchKernelGGL(e->fn, grid, dim3(m.threads), m.lds_bytes, s, g);
+    g.keys = keys;
+    g.keys_pitch = keys_pitch;
+    for (int pass = 0; pass < m.passes; ++pass) {
+        g.d_first = c.d_lo + pass * m.nch * m.nd_per_thread;
+        g.pass_mode = m.passes == 1 ? 0 : pass == 0 ? 1 : pass == m.passes - 1 ? 3 : 2;
+        hipLaunchKernelGGL(e->fn, grid, dim3(m.threads), m.lds_bytes, s, g);
+    }
     return hipGetLastError();
 }
 

@@ -311,6 +311,16 @@ def test_full_size_configs(wslib, gpu_ctx, oracle, cfg):
     assert hit > 0.6, hit   # occluded and band-edge pixels miss; ~0.7-0.9 observed
 
 
+@pytest.mark.parametrize("view,cost", [("left", "ssd"), ("left", "sad"), ("right", "ssd")])
+def test_wide_disparity_range_runs_in_passes(wslib, gpu_ctx, oracle, view, cost):
+    """D beyond what one tile holds: several d-group passes meeting in a key plane."""
+    left, right, _ = make_pair(1400, 24, 1100, seed=55)
+    p = wslib.make_params(wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT, 5, 0, 1100, 1.0, cost)
+    assert wslib.plan(p, left.shape, right.shape)["passes"] >= 2
+    got = run(wslib, gpu_ctx, view, left, right, 5, 0, 1100, cost)
+    assert np.array_equal(got, ref(oracle, view, left, right, 5, 0, 1100, cost))
+
+
 def test_shifted_copy_known_answer_at_full_size(wslib, gpu_ctx):
     rng = np.random.default_rng(11)
     w, h, d0 = 1500, 1000, 137

@@ -68,7 +68,7 @@ def test_plan_covers_the_baseline_configs(wslib):
         p = ws.plan(ws.make_params(ws.VIEW_LEFT, bs, 0, d, 1.0, cost), (h, w), (h, w))
         half = (bs - 1) // 2
         assert p["marching"] == 1, (w, h, d)
-        assert p["d_chunks"] * p["d_per_thread"] >= d
+        assert p["passes"] * p["d_chunks"] * p["d_per_thread"] >= d
         assert p["threads"] % 64 == 0 and p["threads"] <= 1024
         assert p["x_runs"] >= 4
         assert p["threads"] >= p["x_runs"] * p["d_chunks"]
@@ -76,6 +76,8 @@ def test_plan_covers_the_baseline_configs(wslib):
         assert p["strips"] * p["strip_rows"] >= h - 2 * half
         assert p["lds_bytes"] <= 160 * 1024
         assert (p["interior_x0"], p["interior_x1"], p["interior_y0"], p["interior_y1"]) == (half, w - half, half, h - half)
+    wide = ws.plan(ws.make_params(ws.VIEW_LEFT, 7, 0, 4000, 1.0, "ssd"), (500, 6000), (500, 6000))
+    assert wide["marching"] == 1 and wide["passes"] > 1       # any disparity range: d-group passes
     # window sizes without a marching instantiation fall back to the brute-force kernel
     assert ws.plan(ws.make_params(ws.VIEW_LEFT, 21, 0, 64), (100, 200), (100, 200))["marching"] == 0
 
