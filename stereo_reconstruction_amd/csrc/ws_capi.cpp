@@ -101,10 +101,12 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
     if (p->view != WS_VIEW_LINEAR && (p->block_size < 1 || p->block_size > 63))
         return fail(ctx, WS_ERR_ARG, "blockSize %d outside [1,63]", p->block_size);
     if (p->view == WS_VIEW_LINEAR && p->linear_range < 1) return fail(ctx, WS_ERR_ARG, "linear_range < 1");
-    if (p->smooth_factor != 1.0 && p->view == WS_VIEW_LEFT)
+    if (p->view == WS_VIEW_LEFT && (p->smooth_factor > 1.0 || p->smooth_factor < 0.0))
         return fail(ctx, WS_ERR_UNSUPPORTED,
-                    "smoothFactor %.3f in the left view: only 1.0 runs on the device (true raster-order dependency, "
-                    "BlockSearch.cpp:68-73)", p->smooth_factor);
+                    "smoothFactor %.3f in the left view: the device handles 0 <= smoothFactor <= 1 "
+                    "(BlockSearch.cpp:68-73)", p->smooth_factor);
+    if (p->view == WS_VIEW_LEFT && p->smooth_factor != 1.0 && L->width > 4096)
+        return fail(ctx, WS_ERR_UNSUPPORTED, "smoothFactor != 1 in the left view: images up to 4096 columns");
     if (!(p->smooth_factor == p->smooth_factor)) return fail(ctx, WS_ERR_ARG, "smoothFactor is NaN");
     if (p->var_block && p->view == WS_VIEW_RIGHT)
         return fail(ctx, WS_ERR_UNSUPPORTED, "varBlock is not implemented on the device (BlockSearch.cpp:129-142)");
@@ -177,6 +179,21 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
 {
     ws_params q = *p;
     if (q.view == WS_VIEW_LINEAR) q.min_disparity = 0;
+    if (q.view == WS_VIEW_LEFT && q.smooth_factor != 1.0) {
+        // the data-parallel search (smoothFactor 1) gives d1; the raster-order pass does the rest
+        q.smooth_factor = 1.0;
+        int rc = run_search(ctx, &q, L, R, out, out_stride, s);
+        if (rc != WS_OK) return rc;
+        GenericArgs ga{};
+        ga.L = L->data; ga.R = R->data;
+        ga.w1 = L->width; ga.h1 = L->height; ga.s1 = L->stride;
+        ga.w2 = R->width; ga.h2 = R->height; ga.s2 = R->stride;
+        ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
+        ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
+        ga.out = out; ga.out_pitch = out_stride;
+        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, s));
+        return WS_OK;
+    }
     const bool smooth = q.smooth_factor != 1.0 && q.view != WS_VIEW_LEFT && q.min_disparity == 0;
     if (!smooth) return run_search(ctx, &q, L, R, out, out_stride, s);
     q.min_disparity = 1; // the data-parallel part: best candidate among d >= 1

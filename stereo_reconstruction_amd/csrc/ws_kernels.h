@@ -86,6 +86,8 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
+// smoothFactor in [0,1], left view: g.out holds the smoothFactor-1 result on entry
+hipError_t launch_smooth_left(const GenericArgs &g, double s, hipStream_t st);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,

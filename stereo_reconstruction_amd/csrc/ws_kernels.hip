@@ -1259,6 +1259,158 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// smoothFactor in [0,1) for the LEFT view (BlockSearch.cpp:68-73): there the factor reaches any
+// candidate d that equals the upper / left neighbour's stored value -- a true dependency on the
+// neighbours' values in raster order.  With 0 <= s <= 1 a discounted candidate only gets cheaper,
+// so the winner is always one of { d1 = the undiscounted argmin, up, left } (every other d is no
+// better than d1 and loses the tie by the reference's own rule).  So: the ordinary data-parallel
+// search gives d1; one workgroup then walks the rows in order and, inside a row, iterates
+//     v_x <- F_x(v_{x-1})          F_x(l) = lexmin over {d1, up, l} of (distance * s^matches, -d)
+// from the left-independent guess until nothing changes (the fixed point is the sequential
+// result; the iteration count is the longest run a left neighbour's value actually propagates).
+// ------------------------------------------------------------------------------------------
+struct SmoothLeftArgs {
+    const uint8_t *L;
+    const uint8_t *R;
+    int w1, h1, s1, w2, h2, s2;
+    int block_size, max_d, ssd;
+    double s;
+    float *out; // holds d1 on entry, the final map on exit
+    int out_pitch;
+};
+
+__device__ __forceinline__ bool left_candidate_ok(const SmoothLeftArgs &g, int x, int d, int half)
+{
+    return d >= 1 && d <= g.max_d && x - d >= half && x - d < g.w2 - half;
+}
+
+__device__ __forceinline__ double left_dist(const SmoothLeftArgs &g, int x, int y, int d, int half)
+{
+    const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+    const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (x - d - half);
+    const uint32_t c = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+    return g.ssd ? sqrt((double)c) : (double)c;
+}
+
+// candidate (dist, d) beats (bd, bdist) in the reference's iteration (d descending, strict <)
+__device__ __forceinline__ bool left_better(double dist, int d, double bdist, int bd)
+{
+    return dist < bdist || (dist == bdist && d > bd);
+}
+
+constexpr int kSmoothLeftPer = 4; // columns per thread: images up to 4096 wide
+
+__global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftArgs g)
+{
+    extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
+    __shared__ int changed;
+    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (g.block_size - 1) / 2;
+    const int height = min(g.h1, g.h2);
+    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f; // row above the first interior row: border zeros
+    if (half > 0) // (for half == 0 the first row has no upper neighbour at all: zeros never match d >= 1)
+        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
+    __syncthreads();
+    for (int y = half; y < height - half; ++y) {
+        float *orow = g.out + (size_t)y * g.out_pitch;
+        // per column: the fixed ingredients of F_x
+        int d1[kSmoothLeftPer], du[kSmoothLeftPer], lastl[kSmoothLeftPer];
+        double u1[kSmoothLeftPer], uu[kSmoothLeftPer], ul[kSmoothLeftPer];
+        bool act[kSmoothLeftPer];
+#pragma unroll
+        for (int k = 0; k < kSmoothLeftPer; ++k) {
+            const int x = tid + k * nt;
+            act[k] = false;
+            d1[k] = du[k] = 0; lastl[k] = -1;
+            u1[k] = uu[k] = ul[k] = 0.0;
+            if (x < g.w1) {
+                const float v = orow[x];
+                cur[x] = v;
+                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+                    const int d = (int)v;
+                    if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, value x stays
+                        act[k] = true;
+                        d1[k] = d;
+                        u1[k] = left_dist(g, x, y, d, half);
+                        const int up = (int)prev[x];
+                        const bool up_int = (float)up == prev[x];
+                        if (y >= 1 && up_int && up != d && left_candidate_ok(g, x, up, half)) {
+                            du[k] = up;
+                            uu[k] = left_dist(g, x, y, up, half) * g.s;
+                        } else if (y >= 1 && up_int && up == d) {
+                            du[k] = -1; // d1 itself is the upper neighbour's value
+                            u1[k] *= g.s;
+                        }
+                        // the guess without a left neighbour
+                        float gx = (float)d;
+                        if (du[k] > 0 && left_better(uu[k], du[k], u1[k], d)) gx = (float)du[k];
+                        cur[x] = gx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = 0; it < g.w1 + 1; ++it) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSmoothLeftPer; ++k) {
+                const int x = tid + k * nt;
+                if (x >= g.w1) continue;
+                float res = cur[x];
+                if (act[k]) {
+                    // start from d1 (its upper-neighbour factor already in u1), then up, then left
+                    double bdist = u1[k];
+                    int bd = d1[k];
+                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
+                    const int l = (int)lf;
+                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
+                    if (l_ok && l == d1[k]) bdist = bdist * g.s; // the left factor comes second (BlockSearch.cpp:71-73)
+                    if (du[k] > 0) {
+                        double e = uu[k];
+                        if (l_ok && l == du[k]) e = e * g.s;
+                        if (left_better(e, du[k], bdist, bd)) { bdist = e; bd = du[k]; }
+                    }
+                    if (l_ok && l != d1[k] && l != du[k]) {
+                        if (lastl[k] != l) { // distance at the left neighbour's value: cached per column
+                            ul[k] = left_dist(g, x, y, l, half);
+                            lastl[k] = l;
+                        }
+                        const double e = ul[k] * g.s;
+                        if (left_better(e, l, bdist, bd)) { bdist = e; bd = l; }
+                    }
+                    res = (float)bd;
+                }
+                nxt[x] = res;
+                if (res != cur[x]) changed = 1;
+            }
+            __syncthreads();
+            float *t = cur; cur = nxt; nxt = t;
+            const int any = changed;
+            __syncthreads();
+            if (!any) break;
+        }
+        for (int x = tid; x < g.w1; x += nt) {
+            orow[x] = cur[x];
+        }
+        __syncthreads();
+        { float *t = prev; prev = cur; cur = t; }
+    }
+}
+
+hipError_t launch_smooth_left(const GenericArgs &g, double s, hipStream_t st)
+{
+    SmoothLeftArgs a{};
+    a.L = g.L; a.R = g.R; a.w1 = g.w1; a.h1 = g.h1; a.s1 = g.s1; a.w2 = g.w2; a.h2 = g.h2; a.s2 = g.s2;
+    a.block_size = g.block_size; a.max_d = g.max_d; a.ssd = g.ssd; a.s = s;
+    a.out = g.out; a.out_pitch = g.out_pitch;
+    if (g.w1 > kSmoothLeftPer * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a);
+    return hipGetLastError();
+}
+
 // ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
 // There c0 * s^k does not grow with k, so t_0 >= t_1 >= t_2 and a pixel is one of: always 0
 // ("generate"), never 0 ("kill"), or 0 exactly when its left neighbour is ("propagate") -- a

@@ -149,6 +149,24 @@ def test_smooth_factor_right_view_and_linear(wslib, gpu_ctx, oracle, smooth, lev
     assert np.array_equal(got, oracle.linear(left, right, smooth=smooth))
 
 
+@pytest.mark.parametrize("smooth", [0.9, 0.5, 0.0])
+@pytest.mark.parametrize("levels", [256, 3, 2])
+def test_smooth_factor_left_view(wslib, gpu_ctx, oracle, smooth, levels):
+    """Left view: the factor reaches whatever d the upper / left neighbour holds (BlockSearch.cpp:68-73),
+    a true raster-order dependency; the device iterates each row to its fixed point."""
+    if levels == 256:
+        left, right, _ = make_pair(300, 48, 40, seed=41)
+    else:
+        rng = np.random.default_rng(levels)
+        left = (rng.integers(0, levels, size=(48, 300, 3)) * (255 // (levels - 1))).astype(np.uint8)
+        right = (rng.integers(0, levels, size=(48, 300, 3)) * (255 // (levels - 1))).astype(np.uint8)
+    left[10:14, 20:60] = 0
+    for bs, cost, maxd in ((7, "ssd", 40), (5, "sad", 24), (1, "ssd", 12), (17, "ssd", 30)):
+        got = wslib.BlockSearch(left, right, bs, 0, maxd, cost=cost, context=gpu_ctx).computeDisparityMapLeft(smooth)
+        want = oracle.block_left(left, right, bs, 0, maxd, smooth=smooth, cost=cost)
+        assert np.array_equal(got, want), (bs, cost)
+
+
 def test_reference_pipeline_call_on_teddy_sized_pair(wslib, gpu_ctx, oracle):
     """main.cpp:40: computeDisparityMapRight(17, 0, 200, 0.9) at Teddy-H size (900 x 750)."""
     left, right, _ = make_pair(900, 750, 200, seed=13)
@@ -242,8 +260,11 @@ def test_errors_are_reported_not_computed(wslib, gpu_ctx):
         run(wslib, gpu_ctx, "left", left, right, 6, 0, 16, "ssd")
     assert e.value.code == -2                       # even blockSize: the reference throws
     with pytest.raises(wslib.WsError) as e:
-        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapLeft(0.9)
-    assert e.value.code == -3                       # smoothFactor != 1 not on the device yet
+        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapLeft(1.5)
+    assert e.value.code == -3                       # left view: smoothFactor > 1 is not on the device
+    with pytest.raises(wslib.WsError) as e:
+        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapRight(0.9, True)
+    assert e.value.code == -3                       # varBlock is not on the device
     with pytest.raises(wslib.WsError) as e:
         run(wslib, gpu_ctx, "right", left[:30], right, 7, 0, 16, "ssd")
     assert e.value.code == -2

@@ -26,3 +26,5 @@ t("linear 900x750 range 200 s=1.0", ws.VIEW_LINEAR, 900, 750, 1, 0, 200, 1.0, "s
 t("left  2964x1988 9x9 SAD D=512 (config3)", ws.VIEW_LEFT, 2964, 1988, 9, 0, 512, 1.0, "sad", n=5)
 t("left  3840x2160 9x9 SSD D=1024 subpixel (config5)", ws.VIEW_LEFT, 3840, 2160, 9, 0, 1024, 1.0, "ssd", subpixel=True, n=3)
 t("left  450x375 5x5 SAD D=64 (config1 shape)", ws.VIEW_LEFT, 450, 375, 5, 0, 64, 1.0, "sad")
+t("left  900x750 7x7 SSD D=200 s=0.9 (left smooth)", ws.VIEW_LEFT, 900, 750, 7, 0, 200, 0.9, "ssd", n=2)
+t("left  900x750 17x17 SSD D=200 s=0.9 (left smooth)", ws.VIEW_LEFT, 900, 750, 17, 0, 200, 0.9, "ssd", n=2)
