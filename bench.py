@@ -161,12 +161,20 @@ def main():
 
     # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc (one pass per
     # counter) and committed; bench.py does not run the profiler itself
-    traffic = None
+    traffic, valu = None, None
     tfile = os.path.join(ROOT, "profiles", "r01", "traffic_%s.json" % args.workload)
     if os.path.exists(tfile):
         tj = json.load(open(tfile))
         if tj.get("kernel") == info["kernel"]:
             traffic = tj["hbm_bytes_per_launch"]
+            if "sq_insts_valu" in tj:
+                # the bound that actually applies: VALU instruction issue
+                lane_ops = tj["sq_insts_valu"] * 64.0
+                valu = {"lane_ops_per_launch": lane_ops,
+                        "lane_ops_per_hypothesis": round(lane_ops / (float(lw) * lh * max_d), 2),
+                        "achieved_lane_ops_per_s": round(lane_ops / (kernel_ms * 1e-3), 0),
+                        "measured_issue_peak_lane_ops_per_s": tj["valu_issue_peak_lane_ops_per_s"],
+                        "frac": round(lane_ops / (kernel_ms * 1e-3) / tj["valu_issue_peak_lane_ops_per_s"], 3)}
 
     out = {
         "metric": "Mdisparities/s (HxWxD / s) on Middlebury-H pairs",
@@ -189,7 +197,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel": info["kernel"], "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes": alg_bytes,
+                     "algorithmic_bytes": alg_bytes, "valu_issue": valu,
                      "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "
                              "VALU-issue bound, see DESIGN.md for the lane-op ceiling"},
     }

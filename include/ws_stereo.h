@@ -78,7 +78,7 @@ typedef struct {
     int max_disparity;    /* maxDisparity: left tries d = maxD..1, right d = minD..maxD-1 */
     double smooth_factor; /* smoothFactor; any value in the right view / LinearSearch, 0..1 in the left
                              view (its true raster-order dependency) */
-    int var_block;        /* varBlock (right view); not on the device yet */
+    int var_block;        /* varBlock (right view): grow the window while its centred norm < thres */
     double thres;         /* thres for varBlock, default 19.0 (BlockSearch.h:37) */
     int subpixel;         /* extension: parabolic refinement on the aggregated integer cost */
     int linear_range;     /* LinearSearch's hard-coded 200 candidates (LinearSearch.cpp:32) */
@@ -191,6 +191,12 @@ int ws_timer_end(ws_context *ctx, void *stream, float *elapsed_ms);
  */
 int ws_set_profiling(ws_context *ctx, int enable);
 int ws_last_kernel_ms(ws_context *ctx, float *elapsed_ms);
+/*
+ * What the reference prints as "max block size" after computeDisparityMapRight
+ * (BlockSearch.cpp:177): the largest block varBlock grew to in the last right-view call of this
+ * context (block_size itself if nothing grew or varBlock was off).  Synchronises the device.
+ */
+int ws_last_max_block(ws_context *ctx, int block_size, int *max_block);
 /*
  * After a ws_search_* call: the kernel that dominates it and how the path was tiled
  * (name as it appears in a rocprofv3 kernel trace, threads per workgroup, workgroups,

@@ -40,7 +40,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
-           "ws_last_launch_info", "ws_set_tuning",
+           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -136,6 +136,7 @@ def load_library(build_if_missing=False):
     lib.ws_timer_end.argtypes = [vp, vp, P(ctypes.c_float)]
     lib.ws_set_profiling.argtypes = [vp, ci]
     lib.ws_last_kernel_ms.argtypes = [vp, P(ctypes.c_float)]
+    lib.ws_last_max_block.argtypes = [vp, ci, P(ci)]
     lib.ws_last_launch_info.argtypes = [vp, ctypes.c_char_p, ci, P(ci), P(ci), P(ci)]
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
@@ -292,6 +293,11 @@ class WindowSearch:
                                                   ctypes.byref(w), ctypes.byref(l)))
         return {"kernel": name.value.decode(), "threads": t.value, "workgroups": w.value,
                 "lds_bytes": l.value}
+
+    def last_max_block(self, block_size):
+        v = ctypes.c_int()
+        self._check(self._lib.ws_last_max_block(self._h, block_size, ctypes.byref(v)))
+        return v.value
 
     def set_tuning(self, x_runs_per_tile=0, strip_rows=0, threads=0):
         self._check(self._lib.ws_set_tuning(self._h, x_runs_per_tile, strip_rows, threads))

@@ -46,11 +46,12 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, keys, sel, sel_planes, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, keys, bs_plane, max_block, sel, sel_planes, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
     int last_threads = 0, last_wgs = 0, last_lds = 0;
+    bool var_block_ran = false;
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
 };
 
@@ -108,8 +109,10 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
     if (p->view == WS_VIEW_LEFT && p->smooth_factor != 1.0 && L->width > 4096)
         return fail(ctx, WS_ERR_UNSUPPORTED, "smoothFactor != 1 in the left view: images up to 4096 columns");
     if (!(p->smooth_factor == p->smooth_factor)) return fail(ctx, WS_ERR_ARG, "smoothFactor is NaN");
-    if (p->var_block && p->view == WS_VIEW_RIGHT)
-        return fail(ctx, WS_ERR_UNSUPPORTED, "varBlock is not implemented on the device (BlockSearch.cpp:129-142)");
+    if (p->var_block && p->view == WS_VIEW_RIGHT && p->subpixel)
+        return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with varBlock");
+    if (p->var_block && p->view == WS_VIEW_RIGHT && !(p->thres == p->thres))
+        return fail(ctx, WS_ERR_ARG, "thres is NaN");
     if (p->subpixel && p->view == WS_VIEW_LINEAR) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel on LinearSearch");
     if (p->subpixel && p->smooth_factor != 1.0) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
     const int h1 = L->height, w1 = L->width, h2 = R->height, w2 = R->width;
@@ -210,6 +213,10 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
+    if (p->view == WS_VIEW_RIGHT && p->var_block) { // the windows ws_varblock_kernel chose
+        ga.bs_plane = static_cast<const int16_t *>(ctx->bs_plane.p);
+        ga.bs_pitch = (R->width + 63) & ~63;
+    }
     if ((rc = ensure(ctx, ctx->sel_planes, smooth_planes_bytes(R->width, R->height))) != WS_OK) return rc;
     WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch,
                               static_cast<unsigned long long *>(ctx->sel_planes.p), s));
@@ -232,6 +239,22 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
 
+    if (p->view == WS_VIEW_RIGHT) ctx->var_block_ran = false;
+    if (p->view == WS_VIEW_RIGHT && p->var_block) {
+        // per-pixel windows: no sliding sums, one wave per pixel (ws_varblock_kernel)
+        const int bs_pitch = (R->width + 63) & ~63;
+        int rc;
+        if ((rc = ensure(ctx, ctx->bs_plane, (size_t)bs_pitch * R->height * 2)) != WS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->max_block, 64)) != WS_OK) return rc;
+        WS_HIP(ctx, launch_varblock(ga, p->thres, static_cast<int16_t *>(ctx->bs_plane.p), bs_pitch,
+                                    static_cast<int *>(ctx->max_block.p), s));
+        ctx->last_kernel = "ws_varblock_kernel";
+        ctx->last_threads = 256;
+        ctx->last_wgs = (int)(((long long)R->width * R->height + 3) / 4);
+        ctx->last_lds = 0;
+        ctx->var_block_ran = true;
+        return WS_OK;
+    }
     Canon c{};
     MarchLaunch m{};
     Plane ring_a{}, ring_b{};
@@ -355,7 +378,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);
@@ -689,6 +712,19 @@ int ws_last_kernel_ms(ws_context *ctx, float *elapsed_ms)
     if (!ctx->kernel_timed) return fail(ctx, WS_ERR_ARG, "no marching-kernel launch was timed (ws_set_profiling off, or the generic path ran)");
     WS_HIP(ctx, hipEventSynchronize(ctx->evk1));
     WS_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->evk0, ctx->evk1));
+    return WS_OK;
+}
+
+int ws_last_max_block(ws_context *ctx, int block_size, int *max_block)
+{
+    if (!ctx || !max_block) return WS_ERR_ARG;
+    *max_block = block_size;
+    if (!ctx->var_block_ran) return WS_OK;
+    int v = 0;
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    WS_HIP(ctx, hipDeviceSynchronize());
+    WS_HIP(ctx, hipMemcpy(&v, ctx->max_block.p, sizeof v, hipMemcpyDeviceToHost));
+    if (v > block_size) *max_block = v;
     return WS_OK;
 }
 

@@ -76,6 +76,9 @@ struct GenericArgs {
     int skip_x0, skip_x1, skip_y0, skip_y1;
     float *out;
     int out_pitch;
+    // varBlock (right view): per-pixel block size chosen by ws_varblock_kernel, or null
+    const int16_t *bs_plane;
+    int bs_pitch;
 };
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
 // Right-view border ring on the packed (mirrored) planes: one wave per pixel, lanes over d.
@@ -102,6 +105,10 @@ hipError_t launch_outliers(float *map, int mp, int w, int h, int k, float thr_fr
 hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float focal, float baseline, const float k[9],
                                  const uint8_t *bgr, int bstride, float *depth, int zp, float *pos, uint8_t *col,
                                  int input_is_depth, hipStream_t s);
+// varBlock (BlockSearch.cpp:125-145, right view): per-pixel window growth + search, one wave per pixel.
+// bs_plane: w2 x h2 int16 (pitch bs_pitch), max_block: one device int (max grown block size)
+hipError_t launch_varblock(const GenericArgs &g, double thres, int16_t *bs_plane, int bs_pitch, int *max_block,
+                           hipStream_t s);
 // float32 -> float64 widening for CV_64F outputs
 hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
                         hipStream_t s);

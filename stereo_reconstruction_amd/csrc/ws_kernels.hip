@@ -760,6 +760,23 @@ __device__ __forceinline__ uint32_t window_cost(const uint8_t *a, int sa, const 
     return acc;
 }
 
+__device__ __forceinline__ unsigned long long window_cost64(const uint8_t *a, int sa, const uint8_t *b, int sb,
+                                                            int ww, int wh, int ssd)
+{
+    unsigned long long acc = 0; // grown (varBlock) windows can exceed 32 bits
+    for (int r = 0; r < wh; ++r) {
+        const uint8_t *pa = a + (size_t)r * sa;
+        const uint8_t *pb = b + (size_t)r * sb;
+        uint32_t row = 0;
+        for (int i = 0; i < 3 * ww; ++i) {
+            const int d = (int)pa[i] - (int)pb[i];
+            row += ssd ? (uint32_t)(d * d) : (uint32_t)(d < 0 ? -d : d);
+        }
+        acc += row;
+    }
+    return acc;
+}
+
 __device__ __forceinline__ bool black3(const uint8_t *p) { return (p[0] | p[1] | p[2]) == 0; }
 
 // The pixels outside the skip rectangle, enumerated densely: rows above it, rows below it, then
@@ -1053,7 +1070,8 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
     const int height = min(g.h1, g.h2);
     if (g.view == 1) {
         if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
-            const int half = (g.block_size - 1) / 2;
+            const int bsz = g.bs_plane ? (int)g.bs_plane[(size_t)y * g.bs_pitch + x] : g.block_size;
+            const int half = (bsz - 1) / 2;
             const int left = min(x, half), right = min(g.w2 - x - 1, half);
             const int up = min(y, half), down = min(g.h2 - y - 1, half);
             const int ww = left + right, wh = up + down;
@@ -1065,8 +1083,8 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
             } else {
                 const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
                 const int d1 = (int)*o;
-                const uint32_t c0 = window_cost(g.L + (size_t)(y - up) * g.s1 + 3 * (x - left), g.s1, rw, g.s2, ww, wh, g.ssd);
-                const uint32_t c1 = window_cost(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const unsigned long long c0 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const unsigned long long c1 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd);
                 const double area = (double)(ww * wh);
                 const double e1 = (g.ssd ? sqrt((double)c1) : (double)c1) / area;
                 double e0 = (g.ssd ? sqrt((double)c0) : (double)c0) / area;
@@ -1690,6 +1708,103 @@ hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float 
     hipLaunchKernelGGL(ws_depth_vertices_kernel, grid, dim3(256), 0, s, disp, dp, w, h, focal, baseline, k ? k[0] : 1.0f,
                        k ? k[4] : 1.0f, k ? k[2] : 0.0f, k ? k[5] : 0.0f, bgr, bstride, depth, zp,
                        reinterpret_cast<float4 *>(pos), reinterpret_cast<uchar4 *>(col), input_is_depth);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// varBlock (BlockSearch.cpp:125-145, right view): while the window's centred norm is below
+// `thres` the block grows by 4; then the search runs with that pixel's own window.  Windows differ
+// from pixel to pixel, so no sliding sums: one wavefront per pixel, lanes share the window pixels
+// for the texture test and split the disparities for the search; wave-wide sums / min by shuffles.
+// cv::mean / cv::subtract / cv::norm semantics as restated in oracle/ws_oracle.c (OpenCV is
+// un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even(p - mean)), L2 norm.
+// Growth stops when the window no longer changes (the reference would loop forever there).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) ws_varblock_kernel(const GenericArgs g, double thres,
+                                                          int16_t *__restrict__ bs_plane, int bs_pitch,
+                                                          int *__restrict__ max_block)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)g.w2 * g.h2) return; // uniform per wave
+    const int x = (int)(pix % g.w2), y = (int)(pix / g.w2);
+    const int height = min(g.h1, g.h2);
+    float val = 0.0f;
+    int bs = g.block_size;
+    if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+        int hb = (bs - 1) / 2;
+        int left = min(x, hb), right = min(g.w2 - x - 1, hb), up = min(y, hb), down = min(g.h2 - y - 1, hb);
+        for (;;) {
+            const int ww = left + right, wh = up + down, n = ww * wh;
+            double nrm = 0.0;
+            if (n > 0) {
+                const uint8_t *w0 = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                unsigned long long s0 = 0, s1 = 0, s2 = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const uint8_t *p = w0 + (size_t)(i / ww) * g.s2 + 3 * (i % ww);
+                    s0 += p[0]; s1 += p[1]; s2 += p[2];
+                }
+                const double area = (double)ww * (double)wh;
+                const double m0 = (double)wave_sum_u64(s0) / area, m1 = (double)wave_sum_u64(s1) / area,
+                             m2 = (double)wave_sum_u64(s2) / area;
+                unsigned long long acc = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const uint8_t *p = w0 + (size_t)(i / ww) * g.s2 + 3 * (i % ww);
+                    const double v0 = fmin(255.0, fmax(0.0, rint((double)p[0] - m0)));
+                    const double v1 = fmin(255.0, fmax(0.0, rint((double)p[1] - m1)));
+                    const double v2 = fmin(255.0, fmax(0.0, rint((double)p[2] - m2)));
+                    acc += (unsigned long long)(v0 * v0) + (unsigned long long)(v1 * v1) + (unsigned long long)(v2 * v2);
+                }
+                nrm = sqrt((double)wave_sum_u64(acc));
+            }
+            if (!(nrm < thres)) break;
+            bs += 4;
+            hb = (bs - 1) / 2;
+            const int l2 = min(x, hb), r2 = min(g.w2 - x - 1, hb), u2 = min(y, hb), d2 = min(g.h2 - y - 1, hb);
+            if (l2 == left && r2 == right && u2 == up && d2 == down) break; // cannot grow any more
+            left = l2; right = r2; up = u2; down = d2;
+        }
+        // the search with this pixel's window: lanes over d, d ascending inside a lane
+        const int ww = left + right, wh = up + down;
+        unsigned long long bcost = ~0ull;
+        int bd = 0x7fffffff;
+        if (ww > 0 && wh > 0) {
+            const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+            const int d_end = min(g.max_d - 1, g.w1 - right - x - 1);
+            for (int d = g.min_d + lane; d <= d_end; d += 64) {
+                const uint8_t *lw = g.L + (size_t)(y - up) * g.s1 + 3 * (x + d - left);
+                const unsigned long long c = window_cost64(lw, g.s1, rw, g.s2, ww, wh, g.ssd);
+                if (c < bcost) { bcost = c; bd = d; }
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) { // wave-wide lexicographic min of (cost, d)
+            const unsigned long long oc = __shfl_xor(bcost, off, 64);
+            const int od = __shfl_xor(bd, off, 64);
+            if (oc < bcost || (oc == bcost && od < bd)) { bcost = oc; bd = od; }
+        }
+        val = bd == 0x7fffffff ? -(float)x : (float)bd;
+        if (lane == 0 && bs > g.block_size) atomicMax(max_block, bs);
+    }
+    if (lane == 0) {
+        g.out[(size_t)y * g.out_pitch + x] = val;
+        bs_plane[(size_t)y * bs_pitch + x] = (int16_t)min(bs, 32767);
+    }
+}
+
+hipError_t launch_varblock(const GenericArgs &g, double thres, int16_t *bs_plane, int bs_pitch, int *max_block,
+                           hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(max_block, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const long long n = (long long)g.w2 * g.h2;
+    hipLaunchKernelGGL(ws_varblock_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g, thres, bs_plane, bs_pitch,
+                       max_block);
     return hipGetLastError();
 }
 

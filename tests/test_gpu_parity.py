@@ -167,6 +167,25 @@ def test_smooth_factor_left_view(wslib, gpu_ctx, oracle, smooth, levels):
         assert np.array_equal(got, want), (bs, cost)
 
 
+@pytest.mark.parametrize("case", [(5, 19.0, "ssd", 0, 1.0), (7, 10.0, "ssd", 0, 0.9), (3, 60.0, "sad", 1, 1.0),
+                                  (9, 35.0, "ssd", 0, 0.5), (17, 10.0, "ssd", 0, 0.9)])
+def test_var_block_right_view(wslib, gpu_ctx, oracle, case):
+    """varBlock (BlockSearch.cpp:125-145): windows grow by 4 while their centred norm is below thres;
+    also together with smoothFactor, and the "max block size" the reference prints (:177)."""
+    bs, thres, cost, mind, smooth = case
+    left, right, _ = make_pair(170, 52, 24, seed=3)
+    right[5:30, 20:70] = (right[5:30, 20:70] // 32) * 32      # weak texture: windows must grow
+    right[10:20, 90:110] = 128                                 # none at all
+    left[8:25, 30:80] = (left[8:25, 30:80] // 64) * 64
+    right[0:4, 0:9] = 0
+    want, want_mb = oracle.block_right(left, right, bs, mind, 24, smooth=smooth, var_block=True, thres=thres,
+                                       cost=cost, return_max_block=True)
+    got = wslib.BlockSearch(left, right, bs, mind, 24, cost=cost, context=gpu_ctx).computeDisparityMapRight(smooth, True, thres)
+    assert np.array_equal(got, want)
+    assert gpu_ctx.last_max_block(bs) == want_mb
+    assert want_mb > bs or bs == 17
+
+
 def test_reference_pipeline_call_on_teddy_sized_pair(wslib, gpu_ctx, oracle):
     """main.cpp:40: computeDisparityMapRight(17, 0, 200, 0.9) at Teddy-H size (900 x 750)."""
     left, right, _ = make_pair(900, 750, 200, seed=13)
@@ -263,8 +282,8 @@ def test_errors_are_reported_not_computed(wslib, gpu_ctx):
         wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapLeft(1.5)
     assert e.value.code == -3                       # left view: smoothFactor > 1 is not on the device
     with pytest.raises(wslib.WsError) as e:
-        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapRight(0.9, True)
-    assert e.value.code == -3                       # varBlock is not on the device
+        wslib.BlockSearch(left, right, 7, 0, 16, subpixel=True, context=gpu_ctx).computeDisparityMapRight(0.9)
+    assert e.value.code == -3                       # the sub-pixel extension needs smoothFactor 1
     with pytest.raises(wslib.WsError) as e:
         run(wslib, gpu_ctx, "right", left[:30], right, 7, 0, 16, "ssd")
     assert e.value.code == -2
