@@ -1716,7 +1716,7 @@ hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float 
 // `thres` the block grows by 4; then the search runs with that pixel's own window.  Windows differ
 // from pixel to pixel, so no sliding sums: one wavefront per pixel, lanes share the window pixels
 // for the texture test and split the disparities for the search; wave-wide sums / min by shuffles.
-// cv::mean / cv::subtract / cv::norm semantics as restated in oracle/ws_oracle.c (OpenCV is
+// cv::mean / cv::subtract / cv::norm semantics (OpenCV 4.x restated; the library is
 // un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even(p - mean)), L2 norm.
 // Growth stops when the window no longer changes (the reference would loop forever there).
 // ------------------------------------------------------------------------------------------
