@@ -44,6 +44,11 @@ __host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// LDS regions of the target-image rows: a thread's run there starts at quad (X/4)*r + (ND/4)*k, so the
+// region of its m-th quad is only fixed at compile time if the region count divides both
+__host__ __device__ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+__host__ __device__ constexpr int march_nreg_b(int x, int nd) { return gcd_c(x / 4, nd / 4); }
+
 // dwords per LDS region for a row of n dwords split into nreg regions (+1 quad: runs may over-read)
 __host__ __device__ constexpr int march_region_dwords(int n, int nreg)
 {
@@ -284,7 +289,7 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
                                           const uint32_t *runA, int ro_a, const uint32_t *runB,
                                           int ro_b, const int32_t *runBias, int ro_bi, int shift)
 {
-    constexpr int NREG = X / 4;
+    constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
     constexpr int NA = X + WW - 1;
     constexpr int NB = NA + ND - 1;
     constexpr int NBI = X + ND - 1;
@@ -293,9 +298,9 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
 
     uint32_t pa[NA], pb[NB];
     lds_run<NA, NREG>(pa, runA, ro_a);
-    lds_run<NB, NREG>(pb, runB, ro_b);
+    lds_run<NB, NREGB>(pb, runB, ro_b);
     uint32_t bi[NBI];
-    if constexpr (KEY && SSD) lds_run<NBI, NREG>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
+    if constexpr (KEY && SSD) lds_run<NBI, NREGB>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
 
     // two disparities at a time: two independent prefix chains interleave in the issue stream
     // (a v_dot4 needs a wait state before its result can feed the next v_dot4's accumulator)
@@ -329,8 +334,8 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
 template <int X, int ND, int WW, int WH, bool SSD, int MAXT>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
-    static_assert(X % 4 == 0 && ND % X == 0 && ND % 2 == 0, "run starts must stay region aligned");
-    constexpr int NREG = X / 4;
+    static_assert(X % 4 == 0 && ND % 4 == 0, "runs start on 16-byte quads");
+    constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
     constexpr int LT = ilog2c(ND);
     constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
     constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
@@ -343,9 +348,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int NT = blockDim.x, tid = threadIdx.x;
     const int tx = g.nxr * X, dt = g.nch * ND;
     const int n_a = tx + WW - 1, n_b = tx + WW + dt - 2, n_bi = tx + dt - 1;
-    const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREG);
-    const int ro_bi = SSD ? march_region_dwords(n_bi, NREG) : 0;
-    const int a_w = NREG * ro_a, b_w = NREG * ro_b, bi_w = NREG * ro_bi;
+    const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
+    const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
+    const int a_w = NREG * ro_a, b_w = NREGB * ro_b, bi_w = NREGB * ro_bi;
     uint32_t *ringA = smem;
     uint32_t *ringB = ringA + NR * a_w;
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
@@ -371,9 +376,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
     const int r = tid % g.nxr, c = tid / g.nxr;
     const bool worker = c < g.nch;
-    // run starts, in quads of region 0: A at column X*r, B / bias at X*r + ND*(nch-1-c)
+    // run starts (dword offset inside region 0): A at column X*r, B / bias at column X*r + ND*(nch-1-c)
     const int ia = 4 * r;
-    const int ib = 4 * (r + (ND / X) * (g.nch - 1 - (worker ? c : 0)));
+    const int ib = 4 * (((X / 4) * r + (ND / 4) * (g.nch - 1 - (worker ? c : 0))) / NREGB);
     const int d0 = g.d_first + c * ND; // first disparity of this thread's chunk
     const int shift = SSD ? LT + 1 : g.tag_bits;
     // global tie tag of local tag jt is ctag + jt (SSD merge)
@@ -405,9 +410,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
     // prologue: row ra0 (and the bias row of step 0 when the window is one row high)
     stage_row_async<NREG>(ringA, ro_a, gA + (size_t)ra0 * g.pitch_a, n_a, tid, NT);
-    stage_row_async<NREG>(ringB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
+    stage_row_async<NREGB>(ringB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
     if (SSD && WH == 1)
-        stage_row_async<NREG>(reinterpret_cast<uint32_t *>(biasr), ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
+        stage_row_async<NREGB>(reinterpret_cast<uint32_t *>(biasr), ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
     __syncthreads();
 
     int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
@@ -459,9 +464,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         if (nxt_slot == NR) nxt_slot = 0;
         if (a + 1 < nsteps) {
             stage_row_async<NREG>(ringA + nxt_slot * a_w, ro_a, gA + (size_t)(ra0 + a + 1) * g.pitch_a, n_a, tid, NT);
-            stage_row_async<NREG>(ringB + nxt_slot * b_w, ro_b, gB + (size_t)(ra0 + a + 1) * g.pitch_b, n_b, tid, NT);
+            stage_row_async<NREGB>(ringB + nxt_slot * b_w, ro_b, gB + (size_t)(ra0 + a + 1) * g.pitch_b, n_b, tid, NT);
             if (SSD && oi + 1 >= 0)
-                stage_row_async<NREG>(reinterpret_cast<uint32_t *>(biasr + ((oi + 1) & 1) * bi_w), ro_bi,
+                stage_row_async<NREGB>(reinterpret_cast<uint32_t *>(biasr + ((oi + 1) & 1) * bi_w), ro_bi,
                                       gBi + (size_t)(ys + oi + 1) * g.pitch_bi, n_bi, tid, NT);
         }
 
@@ -618,10 +623,10 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     m.strip_rows = ceil_div(out_h, strips);
     m.strips = ceil_div(out_h, m.strip_rows);
     const int dt = m.nch * kND;
-    const int nreg = kX / 4;
+    const int nreg = kX / 4, nregb = march_nreg_b(kX, kND);
     const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
-              b_w = nreg * march_region_dwords(tx + c.ww + dt - 2, nreg),
-              bi_w = nreg * march_region_dwords(tx + dt - 1, nreg);
+              b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
+              bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);
     const int nr = c.wh + 2;
     m.lds_bytes = c.ssd ? (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8
                         : (size_t)(nr * a_w + nr * b_w) * 4 + (size_t)2 * tx * 4;
