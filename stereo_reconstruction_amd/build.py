@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libws_stereo.so")
-SOURCES = ["ws_kernels.hip", "ws_capi.cpp"]
-HEADERS = [os.path.join(CSRC, "ws_kernels.h"),
+SOURCES = ["ws_march.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip", "ws_consumers.hip", "ws_capi.cpp"]
+HEADERS = [os.path.join(CSRC, "ws_kernels.h"), os.path.join(CSRC, "ws_device.h"),
            os.path.join(HERE, "..", "include", "ws_stereo.h")]
 ARCH = "gfx950"
 

@@ -1,0 +1,340 @@
+// ws_border.hip -- literal brute force (generic), right-view border ring, sub-pixel refine, varBlock
+// Part of the gfx950 kernels of the WindowSearch hot path; overview in ws_march.hip.
+#include "ws_device.h"
+
+namespace wsamd {
+
+// ------------------------------------------------------------------------------------------
+// literal brute force on the original images
+// ------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
+{
+    const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
+    int x, y;
+    if (!ring_pixel(g, ow, oh, (long long)blockIdx.x * blockDim.x + threadIdx.x, &x, &y)) return;
+    const int height = min(g.h1, g.h2);
+    float val = 0.0f;
+    if (g.view == 0) { // BlockSearch.cpp:24-86
+        const int half = (g.block_size - 1) / 2;
+        if (y >= half && y < height - half && x >= half && x < g.w1 - half &&
+            !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+            const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+            uint32_t best = 0xffffffffu;
+            int best_cx = 0;
+            for (int cx = x - g.max_d; cx < x; ++cx) {
+                if (cx < half || cx >= g.w2 - half) continue;
+                const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (cx - half);
+                const uint32_t cst = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+                if (cst < best) {
+                    best = cst;
+                    best_cx = cx;
+                }
+            }
+            val = (float)(x - best_cx);
+        }
+    } else if (g.view == 1) { // BlockSearch.cpp:88-179 (varBlock off)
+        if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+            const int half = (g.block_size - 1) / 2;
+            const int left = min(x, half), right = min(g.w2 - x - 1, half);
+            const int up = min(y, half), down = min(g.h2 - y - 1, half);
+            const int ww = left + right, wh = up + down;
+            uint32_t best = 0xffffffffu;
+            int best_cx = 0;
+            if (ww > 0 && wh > 0) { // empty window: 0/0 = NaN never wins (BlockSearch.cpp:158)
+                const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                for (int cx = x + g.min_d; cx < x + g.max_d; ++cx) {
+                    if (cx + right >= g.w1) break;
+                    const uint8_t *lw = g.L + (size_t)(y - up) * g.s1 + 3 * (cx - left);
+                    const uint32_t cst = window_cost(lw, g.s1, rw, g.s2, ww, wh, g.ssd);
+                    if (cst < best) {
+                        best = cst;
+                        best_cx = cx;
+                    }
+                }
+            }
+            val = (float)(best_cx - x);
+        }
+    } else { // LinearSearch.cpp:10-59
+        if (y < g.h1 && !(x < g.w1 && black3(g.L + (size_t)y * g.s1 + 3 * x))) {
+            const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
+            uint32_t best = 0xffffffffu;
+            int col = 0;
+            for (int k = x + g.min_d; k < x + g.linear_range; ++k) {
+                if (k >= g.w1) break;
+                const uint32_t cst = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * k, 0, 1, 1, 1);
+                if (cst < best) {
+                    best = cst;
+                    col = k;
+                }
+            }
+            val = (float)(col - x);
+        }
+    }
+    g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
+// ------------------------------------------------------------------------------------------
+// right-view border ring: clipped windows (BlockSearch.cpp:116-123), one wave per pixel
+//
+// The marching kernel owns the pixels whose (bs-1)^2 window is complete.  On the ring the window
+// is clipped by the image border, so its size changes from pixel to pixel; there are only
+// ~2*half*(W+H) such pixels.  One wavefront takes one pixel: the 64 lanes take 64 consecutive
+// disparities at a time (consecutive lanes read consecutive target pixels), every lane sums its
+// own window on the packed planes, keeps its best candidate, and a wave-wide min over
+// (cost, d) keys -- butterfly of shuffles -- picks the winner with the reference's tie rule.
+// ------------------------------------------------------------------------------------------
+struct RingArgs {
+    const uint32_t *A;
+    const uint32_t *B;
+    int pitch_a, pad_a, pitch_b, pad_b;
+    int wa, ha, wb;          // canonical plane sizes: A = mirrored right image, B = mirrored left
+    int height;              // min(h1, h2)
+    int half, boff, d_lo, d_hi;
+    int ssd, centred;
+    int skip_x0, skip_x1, skip_y0, skip_y1; // marching interior, ORIGINAL coordinates
+    float *out;
+    int out_pitch;
+};
+
+__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    GenericArgs e{}; // only the skip rectangle is used by ring_pixel
+    e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
+    int x, y;
+    if (!ring_pixel(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
+    const int xm = g.wa - 1 - x; // canonical (mirrored) column
+    float val = 0.0f;
+    const uint32_t black = g.centred ? kCentre : 0u;
+    if (y < g.height && g.A[(size_t)y * g.pitch_a + xm + g.pad_a] != black) {
+        const int left = min(x, g.half), right = min(g.wa - x - 1, g.half);
+        const int up = min(y, g.half), down = min(g.ha - y - 1, g.half);
+        const int ww = left + right, wh = up + down;
+        // candidates: d_lo <= d <= d_hi with x + d + right < w1 (BlockSearch.cpp:147-149)
+        const int d_end = min(g.d_hi, g.wb - right - x - 1);
+        long long best = LLONG_MAX;
+        if (ww > 0 && wh > 0) {
+            const int c0 = xm - right + 1; // first window column, canonical
+            const uint32_t *arow0 = g.A + (size_t)(y - up) * g.pitch_a + c0 + g.pad_a;
+            for (int d = g.d_lo + lane; d <= d_end; d += 64) {
+                const uint32_t *brow0 = g.B + (size_t)(y - up) * g.pitch_b + (c0 - d + g.boff + g.pad_b);
+                int32_t cost = 0;
+                for (int r = 0; r < wh; ++r) {
+                    const uint32_t *pa = arow0 + (size_t)r * g.pitch_a;
+                    const uint32_t *pb = brow0 + (size_t)r * g.pitch_b;
+                    if (!g.ssd) {
+                        uint32_t acc = 0;
+                        for (int i = 0; i < ww; ++i) acc = pix_sad(pa[i], pb[i], acc);
+                        cost += (int32_t)acc;
+                    } else if (g.centred) {
+                        uint32_t bb = 0, ab = 0; // sum (a-b)^2 = sum a^2 + [sum b^2 - 2 sum ab]; sum a^2 is the same for every d
+                        for (int i = 0; i < ww; ++i) {
+                            bb = pix_dot<true>(pb[i], pb[i], bb);
+                            ab = pix_dot<true>(pa[i], pb[i], ab);
+                        }
+                        cost += (int32_t)bb - 2 * (int32_t)ab;
+                    } else {
+                        uint32_t bb = 0, ab = 0;
+                        for (int i = 0; i < ww; ++i) {
+                            bb = pix_dot<false>(pb[i], pb[i], bb);
+                            ab = pix_dot<false>(pa[i], pb[i], ab);
+                        }
+                        cost += (int32_t)bb - 2 * (int32_t)ab;
+                    }
+                }
+                const long long key = ((long long)cost << 32) | (uint32_t)d; // ties: smaller d
+                best = min(best, key);
+            }
+        }
+        // wave-wide min: butterfly over the 64 lanes
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+        val = best == LLONG_MAX ? -(float)x : (float)(uint32_t)(best & 0xffffffffll);
+    }
+    if (lane == 0) g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
+hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
+                       hipStream_t s)
+{
+    RingArgs g{};
+    g.A = a.data; g.B = b.data;
+    g.pitch_a = a.pitch; g.pad_a = a.pad; g.pitch_b = b.pitch; g.pad_b = b.pad;
+    g.wa = c.wa; g.ha = c.ha; g.wb = c.wb;
+    g.height = std::min(c.ha, c.hb);
+    g.half = c.wh / 2; // right view: window (bs-1)^2 = (2*half)^2
+    g.boff = c.boff; g.d_lo = c.d_lo; g.d_hi = c.d_hi;
+    g.ssd = c.ssd; g.centred = march_centred(c);
+    g.skip_x0 = skip.skip_x0; g.skip_x1 = skip.skip_x1; g.skip_y0 = skip.skip_y0; g.skip_y1 = skip.skip_y1;
+    g.out = out; g.out_pitch = out_pitch;
+    const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
+    const long long n = (long long)c.wa * c.ha - (inside > 0 ? inside : 0);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ws_ring_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic(const GenericArgs &g, hipStream_t s)
+{
+    const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
+    const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
+    const long long n = (long long)ow * oh - (inside > 0 ? inside : 0);
+    if (n <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(ws_generic_kernel, grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// Sub-pixel refinement (build extension): the integer map is already final; a
+// pixel is refined when d-1, d and d+1 are all candidates the search itself would have tried.
+__global__ void __launch_bounds__(256) ws_refine_kernel(const GenericArgs g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int height = min(g.h1, g.h2);
+    const int half = (g.block_size - 1) / 2;
+    uint32_t cm, c0, cp;
+    float *o;
+    if (g.view == 0) {
+        if (x < half || x >= g.w1 - half || y < half || y >= height - half) return;
+        if (black3(g.L + (size_t)y * g.s1 + 3 * x)) return;
+        o = g.out + (size_t)y * g.out_pitch + x;
+        const int d = (int)*o;
+        const int cx = x - d;
+        // was there any valid candidate, and are both neighbours valid ones?
+        if (d < 1 || d > g.max_d || cx < half || cx >= g.w2 - half) return;
+        const int cxm = cx + 1, cxp = cx - 1;
+        if (!(cxm < x && cxm < g.w2 - half)) return;
+        if (!(cxp >= x - g.max_d && cxp >= half)) return;
+        const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+        const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (cx - half);
+        c0 = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+        cm = window_cost(lw, g.s1, rw + 3, g.s2, g.block_size, g.block_size, g.ssd);
+        cp = window_cost(lw, g.s1, rw - 3, g.s2, g.block_size, g.block_size, g.ssd);
+    } else {
+        if (x >= g.w2 || y >= height) return;
+        if (black3(g.R + (size_t)y * g.s2 + 3 * x)) return;
+        const int left = min(x, half), right = min(g.w2 - x - 1, half);
+        const int up = min(y, half), down = min(g.h2 - y - 1, half);
+        const int ww = left + right, wh = up + down;
+        if (ww <= 0 || wh <= 0) return;
+        o = g.out + (size_t)y * g.out_pitch + x;
+        const int d = (int)*o;
+        const int cx = x + d;
+        if (d < g.min_d || d >= g.max_d || cx + right >= g.w1) return; // fallback value, not a match
+        if (!(cx - 1 >= x + g.min_d && cx - 1 - left >= 0)) return;
+        if (!(cx + 1 < x + g.max_d && cx + 1 + right < g.w1)) return;
+        const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+        const uint8_t *lw = g.L + (size_t)(y - up) * g.s1 + 3 * (cx - left);
+        c0 = window_cost(lw, g.s1, rw, g.s2, ww, wh, g.ssd);
+        cm = window_cost(lw - 3, g.s1, rw, g.s2, ww, wh, g.ssd);
+        cp = window_cost(lw + 3, g.s1, rw, g.s2, ww, wh, g.ssd);
+    }
+    // exact integer numerator / denominator, one float division
+    const long long num = (long long)cm - (long long)cp;
+    const long long den = (long long)cm - 2LL * (long long)c0 + (long long)cp;
+    if (den > 0) *o = *o + (float)((double)num / (2.0 * (double)den));
+}
+
+hipError_t launch_refine(const GenericArgs &g, hipStream_t s)
+{
+    const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
+    dim3 grid(ceil_div(ow, 256), oh);
+    hipLaunchKernelGGL(ws_refine_kernel, grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// varBlock (BlockSearch.cpp:125-145, right view): while the window's centred norm is below
+// `thres` the block grows by 4; then the search runs with that pixel's own window.  Windows differ
+// from pixel to pixel, so no sliding sums: one wavefront per pixel, lanes share the window pixels
+// for the texture test and split the disparities for the search; wave-wide sums / min by shuffles.
+// cv::mean / cv::subtract / cv::norm semantics (OpenCV 4.x restated; the library is
+// un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even(p - mean)), L2 norm.
+// Growth stops when the window no longer changes (the reference would loop forever there).
+// ------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) ws_varblock_kernel(const GenericArgs g, double thres,
+                                                          int16_t *__restrict__ bs_plane, int bs_pitch,
+                                                          int *__restrict__ max_block)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)g.w2 * g.h2) return; // uniform per wave
+    const int x = (int)(pix % g.w2), y = (int)(pix / g.w2);
+    const int height = min(g.h1, g.h2);
+    float val = 0.0f;
+    int bs = g.block_size;
+    if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+        int hb = (bs - 1) / 2;
+        int left = min(x, hb), right = min(g.w2 - x - 1, hb), up = min(y, hb), down = min(g.h2 - y - 1, hb);
+        for (;;) {
+            const int ww = left + right, wh = up + down, n = ww * wh;
+            double nrm = 0.0;
+            if (n > 0) {
+                const uint8_t *w0 = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                unsigned long long s0 = 0, s1 = 0, s2 = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const uint8_t *p = w0 + (size_t)(i / ww) * g.s2 + 3 * (i % ww);
+                    s0 += p[0]; s1 += p[1]; s2 += p[2];
+                }
+                const double area = (double)ww * (double)wh;
+                const double m0 = (double)wave_sum_u64(s0) / area, m1 = (double)wave_sum_u64(s1) / area,
+                             m2 = (double)wave_sum_u64(s2) / area;
+                unsigned long long acc = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const uint8_t *p = w0 + (size_t)(i / ww) * g.s2 + 3 * (i % ww);
+                    const double v0 = fmin(255.0, fmax(0.0, rint((double)p[0] - m0)));
+                    const double v1 = fmin(255.0, fmax(0.0, rint((double)p[1] - m1)));
+                    const double v2 = fmin(255.0, fmax(0.0, rint((double)p[2] - m2)));
+                    acc += (unsigned long long)(v0 * v0) + (unsigned long long)(v1 * v1) + (unsigned long long)(v2 * v2);
+                }
+                nrm = sqrt((double)wave_sum_u64(acc));
+            }
+            if (!(nrm < thres)) break;
+            bs += 4;
+            hb = (bs - 1) / 2;
+            const int l2 = min(x, hb), r2 = min(g.w2 - x - 1, hb), u2 = min(y, hb), d2 = min(g.h2 - y - 1, hb);
+            if (l2 == left && r2 == right && u2 == up && d2 == down) break; // cannot grow any more
+            left = l2; right = r2; up = u2; down = d2;
+        }
+        // the search with this pixel's window: lanes over d, d ascending inside a lane
+        const int ww = left + right, wh = up + down;
+        unsigned long long bcost = ~0ull;
+        int bd = 0x7fffffff;
+        if (ww > 0 && wh > 0) {
+            const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+            const int d_end = min(g.max_d - 1, g.w1 - right - x - 1);
+            for (int d = g.min_d + lane; d <= d_end; d += 64) {
+                const uint8_t *lw = g.L + (size_t)(y - up) * g.s1 + 3 * (x + d - left);
+                const unsigned long long c = window_cost64(lw, g.s1, rw, g.s2, ww, wh, g.ssd);
+                if (c < bcost) { bcost = c; bd = d; }
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) { // wave-wide lexicographic min of (cost, d)
+            const unsigned long long oc = __shfl_xor(bcost, off, 64);
+            const int od = __shfl_xor(bd, off, 64);
+            if (oc < bcost || (oc == bcost && od < bd)) { bcost = oc; bd = od; }
+        }
+        val = bd == 0x7fffffff ? -(float)x : (float)bd;
+        if (lane == 0 && bs > g.block_size) atomicMax(max_block, bs);
+    }
+    if (lane == 0) {
+        g.out[(size_t)y * g.out_pitch + x] = val;
+        bs_plane[(size_t)y * bs_pitch + x] = (int16_t)min(bs, 32767);
+    }
+}
+
+hipError_t launch_varblock(const GenericArgs &g, double thres, int16_t *bs_plane, int bs_pitch, int *max_block,
+                           hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(max_block, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const long long n = (long long)g.w2 * g.h2;
+    hipLaunchKernelGGL(ws_varblock_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g, thres, bs_plane, bs_pitch,
+                       max_block);
+    return hipGetLastError();
+}
+
+} // namespace wsamd

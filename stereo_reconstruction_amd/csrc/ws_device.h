@@ -1,0 +1,121 @@
+// ws_device.h -- small device / host helpers shared by the kernel translation units.
+#pragma once
+
+#include "ws_kernels.h"
+
+#include <limits.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+namespace wsamd {
+
+__host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// LDS regions of the target-image rows: a thread's run there starts at quad (X/4)*r + (ND/4)*k, so the
+// region of its m-th quad is only fixed at compile time if the region count divides both
+__host__ __device__ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+__host__ __device__ constexpr int march_nreg_b(int x, int nd) { return gcd_c(x / 4, nd / 4); }
+
+// dwords per LDS region for a row of n dwords split into nreg regions (+1 quad: runs may over-read)
+__host__ __device__ constexpr int march_region_dwords(int n, int nreg)
+{
+    return 4 * ((((n + 3) >> 2) + nreg - 1) / nreg + 1);
+}
+
+__device__ __forceinline__ uint32_t pix_sad(uint32_t a, uint32_t b, uint32_t acc)
+{
+    return __builtin_amdgcn_sad_u8(a, b, acc); // v_sad_u8: acc + sum |a.b[i] - b.b[i]|
+}
+// SSD cross products.  Windows up to 9x9 use the bytes as they are (v_dot4_u32_u8).  Larger
+// windows would overflow the 32-bit keys, so their planes hold centred pixels (byte - 128, i.e.
+// byte ^ 0x80, 4th byte 0) multiplied by v_dot4_i32_i8: the differences and hence the SSD are
+// unchanged, the products are 4x smaller.  (The signed form measured 18 % slower on MI355X, so it
+// is only used where it is needed.)
+template <bool CENTRED>
+__device__ __forceinline__ uint32_t pix_dot(uint32_t a, uint32_t b, uint32_t acc)
+{
+    if constexpr (CENTRED)
+        return (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)b, (int)acc, false); // v_dot4_i32_i8
+    else
+        return __builtin_amdgcn_udot4(a, b, acc, false); // v_dot4_u32_u8
+}
+constexpr uint32_t kCentre = 0x00808080u;
+// does an SSD window of ww x wh need centred pixels to keep |key| < 2^28 with nd tags per thread?
+__host__ __device__ constexpr bool ssd_needs_centring(int ww, int wh, int nd)
+{
+    return 2LL * ww * wh * 3 * 255 * 255 * nd >= (1LL << 28);
+}
+
+
+__device__ __forceinline__ uint32_t window_cost(const uint8_t *a, int sa, const uint8_t *b, int sb,
+                                                int ww, int wh, int ssd)
+{
+    uint32_t acc = 0;
+    for (int r = 0; r < wh; ++r) {
+        const uint8_t *pa = a + (size_t)r * sa;
+        const uint8_t *pb = b + (size_t)r * sb;
+        for (int i = 0; i < 3 * ww; ++i) {
+            const int d = (int)pa[i] - (int)pb[i];
+            acc += ssd ? (uint32_t)(d * d) : (uint32_t)(d < 0 ? -d : d);
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ unsigned long long window_cost64(const uint8_t *a, int sa, const uint8_t *b, int sb,
+                                                            int ww, int wh, int ssd)
+{
+    unsigned long long acc = 0; // grown (varBlock) windows can exceed 32 bits
+    for (int r = 0; r < wh; ++r) {
+        const uint8_t *pa = a + (size_t)r * sa;
+        const uint8_t *pb = b + (size_t)r * sb;
+        uint32_t row = 0;
+        for (int i = 0; i < 3 * ww; ++i) {
+            const int d = (int)pa[i] - (int)pb[i];
+            row += ssd ? (uint32_t)(d * d) : (uint32_t)(d < 0 ? -d : d);
+        }
+        acc += row;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ bool black3(const uint8_t *p) { return (p[0] | p[1] | p[2]) == 0; }
+
+// The pixels outside the skip rectangle, enumerated densely: rows above it, rows below it, then
+// for the rows beside it the columns left and right of it.
+__device__ __forceinline__ bool ring_pixel(const GenericArgs &g, int ow, int oh, long long idx, int *px, int *py)
+{
+    const long long n_top = (long long)g.skip_y0 * ow;
+    const long long n_bot = (long long)(oh - g.skip_y1) * ow;
+    const int side = g.skip_x0 + (ow - g.skip_x1);
+    const long long n_side = (long long)(g.skip_y1 - g.skip_y0) * side;
+    if (idx < n_top) {
+        *py = (int)(idx / ow);
+        *px = (int)(idx % ow);
+    } else if (idx < n_top + n_bot) {
+        idx -= n_top;
+        *py = g.skip_y1 + (int)(idx / ow);
+        *px = (int)(idx % ow);
+    } else if (idx < n_top + n_bot + n_side) {
+        idx -= n_top + n_bot;
+        *py = g.skip_y0 + (int)(idx / side);
+        const int k = (int)(idx % side);
+        *px = k < g.skip_x0 ? k : g.skip_x1 + (k - g.skip_x0);
+    } else {
+        return false;
+    }
+    return true;
+}
+
+// wave-wide sum by a butterfly of shuffles
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+} // namespace wsamd

@@ -1,0 +1,534 @@
+// ws_smooth.hip -- smoothFactor != 1: raster-order passes for the three views
+// Part of the gfx950 kernels of the WindowSearch hot path; overview in ws_march.hip.
+#include "ws_device.h"
+
+namespace wsamd {
+
+// ------------------------------------------------------------------------------------------
+// smoothFactor != 1 for the right view and LinearSearch
+//
+// There the reference compares a neighbour's stored value (>= 0, or the negative fallback) with
+// x - cx = -d (BlockSearch.cpp:160-165, LinearSearch.cpp:39-44), so the factor can only ever hit
+// d = 0 next to a neighbour whose stored value is 0 (the fallback cases cannot coincide with a
+// pixel that still has candidates).  Since d = 0 is tried first, the pixel's value is
+//     0            if  !(c1 < c0 * s^k)      k = [up == 0] + [left == 0]
+//     argmin_{d>=1}  otherwise
+// with c0 / c1 the reference's doubles (sqrt, / area, successive multiplications).  The search for
+// d >= 1 is the ordinary data-parallel search; what is left is a boolean recurrence in raster
+// order, solved row by row with a scan over function composition.
+// ------------------------------------------------------------------------------------------
+constexpr uint8_t kSelFixed = 0x80; // value in the map is final; otherwise bits 0..2 = t_0..t_2
+constexpr uint8_t kSelZero = 0x40;  // with kSelFixed: that final value is 0
+
+__global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArgs g, double s,
+                                                                uint8_t *__restrict__ sel, int sel_pitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= g.w2 || y >= g.h2) return;
+    float *o = g.out + (size_t)y * g.out_pitch + x;
+    uint8_t code = kSelFixed;
+    float val = 0.0f;
+    const int height = min(g.h1, g.h2);
+    if (g.view == 1) {
+        if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+            const int bsz = g.bs_plane ? (int)g.bs_plane[(size_t)y * g.bs_pitch + x] : g.block_size;
+            const int half = (bsz - 1) / 2;
+            const int left = min(x, half), right = min(g.w2 - x - 1, half);
+            const int up = min(y, half), down = min(g.h2 - y - 1, half);
+            const int ww = left + right, wh = up + down;
+            const bool any = ww > 0 && wh > 0 && g.max_d > 0 && x + right < g.w1;
+            if (!any) {
+                val = -(float)x; // no candidate at all: stores -x (BlockSearch.cpp:174)
+            } else if (!(g.max_d > 1 && x + 1 + right < g.w1)) {
+                val = 0.0f; // d = 0 is the only candidate
+            } else {
+                const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                const int d1 = (int)*o;
+                const unsigned long long c0 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const unsigned long long c1 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const double area = (double)(ww * wh);
+                const double e1 = (g.ssd ? sqrt((double)c1) : (double)c1) / area;
+                double e0 = (g.ssd ? sqrt((double)c0) : (double)c0) / area;
+                code = 0;
+                if (e1 < e0) code |= 1;
+                e0 *= s;
+                if (e1 < e0) code |= 2;
+                e0 *= s;
+                if (e1 < e0) code |= 4;
+                val = (float)d1;
+            }
+        }
+    } else { // LinearSearch: black test on the left pixel, distance of single pixels
+        if (y < g.h1 && !(x < g.w1 && black3(g.L + (size_t)y * g.s1 + 3 * x))) {
+            if (!(x < g.w1)) {
+                val = -(float)x;
+            } else if (!(g.linear_range > 1 && x + 1 < g.w1)) {
+                val = 0.0f;
+            } else {
+                const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
+                const int d1 = (int)*o;
+                const uint32_t c0 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * x, 0, 1, 1, 1);
+                const uint32_t c1 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * (x + d1), 0, 1, 1, 1);
+                const double e1 = sqrt((double)c1);
+                double e0 = sqrt((double)c0);
+                code = 0;
+                if (e1 < e0) code |= 1;
+                e0 *= s;
+                if (e1 < e0) code |= 2;
+                e0 *= s;
+                if (e1 < e0) code |= 4;
+                val = (float)d1;
+            }
+        }
+    }
+    *o = val;
+    if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
+    sel[(size_t)y * sel_pitch + x] = code;
+}
+
+// compose two maps {0,1}->{0,1} stored as bit0 = f(0), bit1 = f(1):  (b o a)(v) = b(a(v))
+__device__ __forceinline__ uint32_t compose2(uint32_t a, uint32_t b)
+{
+    const uint32_t r0 = (b >> (a & 1)) & 1, r1 = (b >> ((a >> 1) & 1)) & 1;
+    return r0 | (r1 << 1);
+}
+
+// One workgroup walks the rows in order.  Per row every thread owns `per` consecutive columns,
+// composes their transition maps, the workgroup scans the compositions, and each thread replays
+// its columns with the incoming "left neighbour is 0" bit.
+__global__ void __launch_bounds__(1024) ws_smooth_resolve_kernel(float *out, int out_pitch, int w, int rows,
+                                                                 const uint8_t *__restrict__ sel, int sel_pitch)
+{
+    extern __shared__ uint8_t zrow[]; // zero flags of the previous row, then 16 words of wave totals
+    uint32_t *wave_tot = reinterpret_cast<uint32_t *>(zrow + ((w + 3) & ~3));
+    const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (w + nt - 1) / nt;
+    const int x0 = tid * per, x1 = min(x0 + per, w);
+    for (int x = tid; x < w; x += nt) zrow[x] = 0; // y = 0 has no upper neighbour
+    __syncthreads();
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *srow = sel + (size_t)y * sel_pitch;
+        float *orow = out + (size_t)y * out_pitch;
+        // 1. composition of this thread's columns
+        uint32_t f = 2; // identity: f(0)=0, f(1)=1
+        for (int x = x0; x < x1; ++x) {
+            const uint32_t c = srow[x];
+            uint32_t gmap;
+            if (c & kSelFixed) {
+                const uint32_t z = orow[x] == 0.0f;
+                gmap = z | (z << 1);
+            } else {
+                const uint32_t zu = zrow[x];
+                gmap = (((c >> zu) & 1) ^ 1) | ((((c >> (zu + 1)) & 1) ^ 1) << 1);
+            }
+            f = compose2(f, gmap);
+        }
+        // 2. exclusive scan of the compositions over the workgroup
+        uint32_t incl = f;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t prev = __shfl_up(incl, off, 64);
+            if (lane >= off) incl = compose2(prev, incl);
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t before = 2; // maps of all earlier waves
+        for (int k = 0; k < wv; ++k) before = compose2(before, wave_tot[k]);
+        uint32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 2;
+        excl = compose2(before, excl);
+        uint32_t b = excl & 1; // column 0 has no left neighbour: start from 0
+        // 3. replay
+        for (int x = x0; x < x1; ++x) {
+            const uint32_t c = srow[x];
+            uint32_t z;
+            if (c & kSelFixed) {
+                z = orow[x] == 0.0f;
+            } else {
+                const uint32_t k = zrow[x] + b;
+                z = ((c >> k) & 1) ^ 1;
+                if (z) orow[x] = 0.0f;
+            }
+            b = z;
+        }
+        __syncthreads(); // everyone has read zrow / wave_tot of this row
+        b = excl & 1;
+        for (int x = x0; x < x1; ++x) { // store this row's flags for the next one
+            const uint32_t c = srow[x];
+            const uint32_t z = orow[x] == 0.0f;
+            (void)c;
+            zrow[x] = (uint8_t)z;
+        }
+        __syncthreads();
+    }
+}
+
+// The same recurrence for images up to 64 * PER columns wide, on ONE wavefront: every lane owns
+// PER consecutive columns, keeps the previous row's zero flags in a 64-bit mask, and the row scan
+// is six shuffles -- no barrier.  The codes arrive in chunks of rows by LDS-DMA, one chunk ahead,
+// so the serial walk over the rows never waits for HBM.
+template <int PER>
+__global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, int out_pitch, int w, int rows,
+                                                                    const uint8_t *__restrict__ sel, int sel_pitch,
+                                                                    int chunk_rows)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    extern __shared__ uint4 ws_smem4[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
+    const int lane = threadIdx.x;
+    const int x0 = lane * PER;
+    const int chunk_bytes = chunk_rows * sel_pitch; // multiple of 1024: sel_pitch % 64 == 0, chunk_rows % 16 == 0
+    const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    // the sel plane is allocated with (rows rounded up to chunk_rows) rows, so whole chunks may be copied
+    for (int o = lane * 16; o < chunk_bytes; o += 1024)
+        __builtin_amdgcn_global_load_lds((glb_void *)(sel + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
+    unsigned long long zprev = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // chunk c has landed
+        const uint8_t *cur_buf = lds + (c & 1) * chunk_bytes;
+        if (c + 1 < nchunks) {
+            const uint8_t *src = sel + (size_t)(c + 1) * chunk_bytes;
+            uint8_t *dst = lds + ((c + 1) & 1) * chunk_bytes;
+            for (int o = lane * 16; o < chunk_bytes; o += 1024)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
+        }
+        const int y_end = min((c + 1) * chunk_rows, rows);
+        for (int y = c * chunk_rows; y < y_end; ++y) {
+            const uint8_t *srow = cur_buf + (y - c * chunk_rows) * sel_pitch + x0;
+            uint32_t cur[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) cur[k] = (x0 + k < w) ? srow[k] : kSelFixed;
+            uint32_t f = 2;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t cc = cur[k];
+                const uint32_t zu = (uint32_t)(zprev >> k) & 1u;
+                const uint32_t zf = (cc >> 6) & 1u;
+                const uint32_t gm = (cc & kSelFixed) ? (zf | (zf << 1))
+                                                     : ((((cc >> zu) & 1u) ^ 1u) | ((((cc >> (zu + 1)) & 1u) ^ 1u) << 1));
+                f = compose2(f, gm);
+            }
+            uint32_t incl = f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t prev = __shfl_up(incl, off, 64);
+                if (lane >= off) incl = compose2(prev, incl);
+            }
+            uint32_t excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 2;
+            uint32_t b = excl & 1u; // column 0 has no left neighbour
+            unsigned long long znew = 0;
+            float *orow = out + (size_t)y * out_pitch + x0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t cc = cur[k];
+                uint32_t z;
+                if (cc & kSelFixed) {
+                    z = (cc >> 6) & 1u;
+                } else {
+                    const uint32_t kk = ((uint32_t)(zprev >> k) & 1u) + b;
+                    z = ((cc >> kk) & 1u) ^ 1u;
+                    if (z) orow[k] = 0.0f;
+                }
+                znew |= (unsigned long long)z << k;
+                b = z;
+            }
+            zprev = znew;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// smoothFactor in [0,1) for the LEFT view (BlockSearch.cpp:68-73): there the factor reaches any
+// candidate d that equals the upper / left neighbour's stored value -- a true dependency on the
+// neighbours' values in raster order.  With 0 <= s <= 1 a discounted candidate only gets cheaper,
+// so the winner is always one of { d1 = the undiscounted argmin, up, left } (every other d is no
+// better than d1 and loses the tie by the reference's own rule).  So: the ordinary data-parallel
+// search gives d1; one workgroup then walks the rows in order and, inside a row, iterates
+//     v_x <- F_x(v_{x-1})          F_x(l) = lexmin over {d1, up, l} of (distance * s^matches, -d)
+// from the left-independent guess until nothing changes (the fixed point is the sequential
+// result; the iteration count is the longest run a left neighbour's value actually propagates).
+// ------------------------------------------------------------------------------------------
+struct SmoothLeftArgs {
+    const uint8_t *L;
+    const uint8_t *R;
+    int w1, h1, s1, w2, h2, s2;
+    int block_size, max_d, ssd;
+    double s;
+    float *out; // holds d1 on entry, the final map on exit
+    int out_pitch;
+};
+
+__device__ __forceinline__ bool left_candidate_ok(const SmoothLeftArgs &g, int x, int d, int half)
+{
+    return d >= 1 && d <= g.max_d && x - d >= half && x - d < g.w2 - half;
+}
+
+__device__ __forceinline__ double left_dist(const SmoothLeftArgs &g, int x, int y, int d, int half)
+{
+    const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+    const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (x - d - half);
+    const uint32_t c = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+    return g.ssd ? sqrt((double)c) : (double)c;
+}
+
+// candidate (dist, d) beats (bd, bdist) in the reference's iteration (d descending, strict <)
+__device__ __forceinline__ bool left_better(double dist, int d, double bdist, int bd)
+{
+    return dist < bdist || (dist == bdist && d > bd);
+}
+
+constexpr int kSmoothLeftPer = 4; // columns per thread: images up to 4096 wide
+
+__global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftArgs g)
+{
+    extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
+    __shared__ int changed;
+    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (g.block_size - 1) / 2;
+    const int height = min(g.h1, g.h2);
+    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f; // row above the first interior row: border zeros
+    if (half > 0) // (for half == 0 the first row has no upper neighbour at all: zeros never match d >= 1)
+        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
+    __syncthreads();
+    for (int y = half; y < height - half; ++y) {
+        float *orow = g.out + (size_t)y * g.out_pitch;
+        // per column: the fixed ingredients of F_x
+        int d1[kSmoothLeftPer], du[kSmoothLeftPer], lastl[kSmoothLeftPer];
+        double u1[kSmoothLeftPer], uu[kSmoothLeftPer], ul[kSmoothLeftPer];
+        bool act[kSmoothLeftPer];
+#pragma unroll
+        for (int k = 0; k < kSmoothLeftPer; ++k) {
+            const int x = tid + k * nt;
+            act[k] = false;
+            d1[k] = du[k] = 0; lastl[k] = -1;
+            u1[k] = uu[k] = ul[k] = 0.0;
+            if (x < g.w1) {
+                const float v = orow[x];
+                cur[x] = v;
+                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+                    const int d = (int)v;
+                    if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, value x stays
+                        act[k] = true;
+                        d1[k] = d;
+                        u1[k] = left_dist(g, x, y, d, half);
+                        const int up = (int)prev[x];
+                        const bool up_int = (float)up == prev[x];
+                        if (y >= 1 && up_int && up != d && left_candidate_ok(g, x, up, half)) {
+                            du[k] = up;
+                            uu[k] = left_dist(g, x, y, up, half) * g.s;
+                        } else if (y >= 1 && up_int && up == d) {
+                            du[k] = -1; // d1 itself is the upper neighbour's value
+                            u1[k] *= g.s;
+                        }
+                        // the guess without a left neighbour
+                        float gx = (float)d;
+                        if (du[k] > 0 && left_better(uu[k], du[k], u1[k], d)) gx = (float)du[k];
+                        cur[x] = gx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = 0; it < g.w1 + 1; ++it) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSmoothLeftPer; ++k) {
+                const int x = tid + k * nt;
+                if (x >= g.w1) continue;
+                float res = cur[x];
+                if (act[k]) {
+                    // start from d1 (its upper-neighbour factor already in u1), then up, then left
+                    double bdist = u1[k];
+                    int bd = d1[k];
+                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
+                    const int l = (int)lf;
+                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
+                    if (l_ok && l == d1[k]) bdist = bdist * g.s; // the left factor comes second (BlockSearch.cpp:71-73)
+                    if (du[k] > 0) {
+                        double e = uu[k];
+                        if (l_ok && l == du[k]) e = e * g.s;
+                        if (left_better(e, du[k], bdist, bd)) { bdist = e; bd = du[k]; }
+                    }
+                    if (l_ok && l != d1[k] && l != du[k]) {
+                        if (lastl[k] != l) { // distance at the left neighbour's value: cached per column
+                            ul[k] = left_dist(g, x, y, l, half);
+                            lastl[k] = l;
+                        }
+                        const double e = ul[k] * g.s;
+                        if (left_better(e, l, bdist, bd)) { bdist = e; bd = l; }
+                    }
+                    res = (float)bd;
+                }
+                nxt[x] = res;
+                if (res != cur[x]) changed = 1;
+            }
+            __syncthreads();
+            float *t = cur; cur = nxt; nxt = t;
+            const int any = changed;
+            __syncthreads();
+            if (!any) break;
+        }
+        for (int x = tid; x < g.w1; x += nt) {
+            orow[x] = cur[x];
+        }
+        __syncthreads();
+        { float *t = prev; prev = cur; cur = t; }
+    }
+}
+
+hipError_t launch_smooth_left(const GenericArgs &g, double s, hipStream_t st)
+{
+    SmoothLeftArgs a{};
+    a.L = g.L; a.R = g.R; a.w1 = g.w1; a.h1 = g.h1; a.s1 = g.s1; a.w2 = g.w2; a.h2 = g.h2; a.s2 = g.s2;
+    a.block_size = g.block_size; a.max_d = g.max_d; a.ssd = g.ssd; a.s = s;
+    a.out = g.out; a.out_pitch = g.out_pitch;
+    if (g.w1 > kSmoothLeftPer * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a);
+    return hipGetLastError();
+}
+
+// ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
+// There c0 * s^k does not grow with k, so t_0 >= t_1 >= t_2 and a pixel is one of: always 0
+// ("generate"), never 0 ("kill"), or 0 exactly when its left neighbour is ("propagate") -- a
+// carry chain.  With the codes packed into bit planes (64 columns per word) one lane resolves 64
+// columns with a single 64-bit addition (A = g|p, B = g: the carries of A+B are the chain), and
+// the carries between the lanes' words come from the same addition on two ballot masks in the
+// scalar unit.  ~40 bit operations per row for the whole image width.
+__global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__restrict__ sel, int sel_pitch, int w,
+                                                               unsigned long long *__restrict__ planes, int nwp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const uint32_t c = x < w ? sel[(size_t)y * sel_pitch + x] : kSelFixed; // beyond the row: fixed, non-zero
+    const bool fixed = c & kSelFixed;
+    const unsigned long long t0 = __ballot(!fixed && (c & 1)), t1 = __ballot(!fixed && (c & 2)),
+                             t2 = __ballot(!fixed && (c & 4)), fx = __ballot(fixed),
+                             zf = __ballot(fixed && (c & kSelZero));
+    if ((threadIdx.x & 63) == 0 && (x >> 6) < nwp) {
+        unsigned long long *row = planes + (size_t)y * 5 * nwp + (x >> 6);
+        row[0] = t0; row[nwp] = t1; row[2 * nwp] = t2; row[3 * nwp] = fx; row[4 * nwp] = zf;
+    }
+}
+
+__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const unsigned long long *__restrict__ planes, int nwp,
+                                                                    int rows, unsigned long long *__restrict__ zplane,
+                                                                    int chunk_rows)
+{
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    extern __shared__ uint4 ws_smem4[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
+    const int lane = threadIdx.x;
+    const int row_bytes = 5 * nwp * 8; // nwp is even: a multiple of 16 bytes
+    const int chunk_bytes = chunk_rows * row_bytes;
+    const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    const uint8_t *src0 = reinterpret_cast<const uint8_t *>(planes);
+    for (int o = lane * 16; o < chunk_bytes; o += 1024)
+        __builtin_amdgcn_global_load_lds((glb_void *)(src0 + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
+    unsigned long long zprev = 0;
+    const bool active = lane < nwp;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t *cur = lds + (c & 1) * chunk_bytes;
+        if (c + 1 < nchunks) {
+            const uint8_t *src = src0 + (size_t)(c + 1) * chunk_bytes;
+            uint8_t *dst = lds + ((c + 1) & 1) * chunk_bytes;
+            for (int o = lane * 16; o < chunk_bytes; o += 1024)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
+        }
+        const int y_end = min((c + 1) * chunk_rows, rows);
+        for (int y = c * chunk_rows; y < y_end; ++y) {
+            const unsigned long long *row = reinterpret_cast<const unsigned long long *>(cur + (size_t)(y - c * chunk_rows) * row_bytes);
+            unsigned long long g = 0, p = 0;
+            if (active) {
+                const unsigned long long t0 = row[lane], t1 = row[nwp + lane], t2 = row[2 * nwp + lane],
+                                         fx = row[3 * nwp + lane], zf = row[4 * nwp + lane];
+                // zero when the left neighbour is not / is zero, given the upper neighbour's flag
+                unsigned long long n0 = ~((t0 & ~zprev) | (t1 & zprev)), n1 = ~((t1 & ~zprev) | (t2 & zprev));
+                n0 = (n0 & ~fx) | zf;
+                n1 = (n1 & ~fx) | zf;
+                g = n0 & n1;
+                p = n1 & ~n0;
+            }
+            const unsigned long long A = g | p, B = g, S0 = A + B;
+            const bool cout0 = S0 < A, cout1 = cout0 || S0 == ~0ull;
+            // carries between the lanes' words: the same adder on the ballots (scalar unit)
+            const unsigned long long gw = __ballot(cout0), pw = __ballot(cout1 && !cout0);
+            const unsigned long long aw = gw | pw, sw = aw + gw, cw = sw ^ aw ^ gw; // bit l = carry into lane l
+            const unsigned long long cin = (cw >> lane) & 1ull; // column 0 of the row: no left neighbour
+            const unsigned long long S = S0 + cin;
+            const unsigned long long carries = S ^ A ^ B; // bit k = carry into column k
+            const unsigned long long cout = cin ? (unsigned long long)cout1 : (unsigned long long)cout0;
+            const unsigned long long z = (carries >> 1) | (cout << 63);
+            if (active) zplane[(size_t)y * nwp + lane] = z;
+            zprev = z;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_smooth_apply_kernel(float *out, int out_pitch, int w, int rows,
+                                                              const uint8_t *__restrict__ sel, int sel_pitch,
+                                                              const unsigned long long *__restrict__ zplane, int nwp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= rows) return;
+    if (sel[(size_t)y * sel_pitch + x] & kSelFixed) return;
+    if ((zplane[(size_t)y * nwp + (x >> 6)] >> (x & 63)) & 1ull) out[(size_t)y * out_pitch + x] = 0.0f;
+}
+
+int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
+
+size_t smooth_planes_bytes(int w, int h)
+{
+    const int nwp = round_up(ceil_div(w, 64), 2);
+    return (size_t)(h + 64) * 6 * nwp * 8; // 5 code planes + the resolved plane
+}
+
+hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
+                         hipStream_t st)
+{
+    dim3 grid(ceil_div(g.w2, 256), g.h2);
+    hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int rows = std::min(g.h1, g.h2);
+    const int nwords = ceil_div(g.w2, 64);
+    if (s >= 0.0 && s <= 1.0 && nwords <= 64 && planes) {
+        const int nwp = round_up(nwords, 2);
+        unsigned long long *zplane = planes + (size_t)(g.h2 + 64) * 5 * nwp;
+        hipLaunchKernelGGL(ws_smooth_planes_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, sel, sel_pitch,
+                           g.w2, planes, nwp);
+        int chunk = 24576 / (5 * nwp * 8);
+        if (chunk > 64) chunk = 64;
+        if (chunk < 1) chunk = 1;
+        hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel, dim3(1), dim3(64), (size_t)2 * chunk * 5 * nwp * 8, st, planes,
+                           nwp, rows, zplane, chunk);
+        hipLaunchKernelGGL(ws_smooth_apply_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch,
+                           g.w2, rows, sel, sel_pitch, zplane, nwp);
+        return hipGetLastError();
+    }
+    const int per = ceil_div(g.w2, 64);
+    // rows per LDS chunk: two chunks in at most 64 KB, a multiple of 16 rows (whole 1 KB DMA pieces)
+    int chunk = (32768 / sel_pitch) / 16 * 16;
+    if (chunk > 64) chunk = 64;
+    const size_t wl = (size_t)2 * chunk * sel_pitch;
+    if (per <= 8 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<8>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else if (per <= 16 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<16>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else if (per <= 32 && chunk >= 16)
+        hipLaunchKernelGGL(ws_smooth_resolve_wave_kernel<32>, dim3(1), dim3(64), wl, st, g.out, g.out_pitch, g.w2, rows, sel, sel_pitch, chunk);
+    else {
+        const size_t lds = (size_t)((g.w2 + 3) & ~3) + 16 * sizeof(uint32_t);
+        hipLaunchKernelGGL(ws_smooth_resolve_kernel, dim3(1), dim3(1024), lds, st, g.out, g.out_pitch, g.w2, rows, sel,
+                           sel_pitch);
+    }
+    return hipGetLastError();
+}
+
+} // namespace wsamd

@@ -18,7 +18,8 @@ def build(specs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-DWS_X=" + x, "-DWS_ND=" + nd, "-DWS_MAXT=" + maxt] + ["-D" + e for e in extra] + [
                "-Rpass-analysis=kernel-resource-usage", "-o", out,
-               os.path.join(CSRC, "ws_kernels.hip"), os.path.join(CSRC, "ws_capi.cpp")]
+               ] + [os.path.join(CSRC, f) for f in ("ws_march.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip",
+                                                     "ws_consumers.hip", "ws_capi.cpp")]
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         if r.returncode != 0:
             print(spec, "BUILD FAILED", r.stderr[-2000:]); continue
