@@ -1,0 +1,28 @@
+"""One-off evidence run: compare WHOLE device maps with the oracle at BASELINE.json's full sizes
+(the test-suite compares row bands to stay fast).  Usage on the GPU box:
+    python tools/full_compare.py config2 config3 config5 > gpurun_out/full_compare.txt
+"""
+import os, sys, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import stereo_reconstruction_amd as ws
+from stereo_reconstruction_amd.synthetic import make_pair
+from oracle import oracle
+from bench import WORKLOADS, host_cores
+
+ctx = ws.WindowSearch(0)
+for name in sys.argv[1:]:
+    w, h, bs, cost, maxd, seed = WORKLOADS[name]
+    left, right, _ = make_pair(w, h, maxd, seed)
+    for view in ("left", "right"):
+        b = ws.BlockSearch(left, right, bs, 0, maxd, cost=cost, context=ctx)
+        t0 = time.time()
+        got = b.computeDisparityMapLeft(1.0) if view == "left" else b.computeDisparityMapRight(1.0)
+        t1 = time.time()
+        f = oracle.block_left if view == "left" else oracle.block_right
+        want = f(left, right, bs, 0, maxd, cost=cost, threads=host_cores())
+        t2 = time.time()
+        same = bool(np.array_equal(got, want))
+        print("%s %s view %dx%d %dx%d %s D=%d: identical=%s  mismatches=%d  sha1(device map)=%s  device call %.1f ms, oracle %.1f s on %d threads"
+              % (name, view, w, h, bs, bs, cost.upper(), maxd, same, int((got != want).sum()),
+                 hashlib.sha1(np.ascontiguousarray(got).tobytes()).hexdigest()[:16], (t1 - t0) * 1e3, t2 - t1, host_cores()), flush=True)
