@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(256) ws_refine_kernel(const GenericArgs g)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
+    // the marching interior, when there is one, is refined on the packed planes (below)
+    if (x >= g.skip_x0 && x < g.skip_x1 && y >= g.skip_y0 && y < g.skip_y1) return;
     const int height = min(g.h1, g.h2);
     const int half = (g.block_size - 1) / 2;
     uint32_t cm, c0, cp;
@@ -235,6 +237,79 @@ __global__ void __launch_bounds__(256) ws_refine_kernel(const GenericArgs g)
     const long long num = (long long)cm - (long long)cp;
     const long long den = (long long)cm - 2LL * (long long)c0 + (long long)cp;
     if (den > 0) *o = *o + (float)((double)num / (2.0 * (double)den));
+}
+
+// The same refinement for the marching interior (complete windows) on the packed planes: one
+// v_sad_u8 / two v_dot4 per pixel pair instead of byte arithmetic.  sum a^2 cancels in both the
+// numerator and the denominator, so only sum b^2 - 2 sum ab is needed for the three candidates.
+struct RefineArgs {
+    const uint32_t *A;
+    const uint32_t *B;
+    int pitch_a, pad_a, pitch_b, pad_b;
+    int wa, ww, wh, wx0, wy0, boff;
+    int d_lo, d_hi, b_lo, b_hi;
+    int ox0, ox1, oy0, oy1;
+    int ssd, centred, mirror;
+    float *out;
+    int out_pitch;
+};
+
+template <bool SSD, bool CENTRED>
+__global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs g)
+{
+    const int x = g.ox0 + blockIdx.x * blockDim.x + threadIdx.x; // canonical column
+    const int y = g.oy0 + blockIdx.y;
+    if (x >= g.ox1 || y >= g.oy1) return;
+    if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] == (CENTRED ? kCentre : 0u)) return; // black pixel
+    float *o = g.out + (size_t)y * g.out_pitch + (g.mirror ? g.wa - 1 - x : x);
+    const int d = (int)*o;
+    const int xb = x - d + g.boff; // target centre of the winner
+    if (d < g.d_lo || d > g.d_hi || xb < g.b_lo || xb > g.b_hi) return; // fallback value, not a match
+    if (d - 1 < g.d_lo || d + 1 > g.d_hi || xb - 1 < g.b_lo || xb + 1 > g.b_hi) return;
+    long long cm = 0, c0 = 0, cp = 0; // costs at d-1 (target column +1), d, d+1 (target column -1)
+    for (int r = 0; r < g.wh; ++r) {
+        const uint32_t *pa = g.A + (size_t)(y + g.wy0 + r) * g.pitch_a + (x + g.wx0 + g.pad_a);
+        const uint32_t *pb = g.B + (size_t)(y + g.wy0 + r) * g.pitch_b + (xb + g.wx0 + g.pad_b);
+        uint32_t sm = 0, s0 = 0, sp = 0, bm = 0, b0 = 0, bp = 0;
+        for (int i = 0; i < g.ww; ++i) {
+            const uint32_t a = pa[i], vm = pb[i + 1], v0 = pb[i], vp = pb[i - 1];
+            if constexpr (SSD) {
+                sm = pix_dot<CENTRED>(a, vm, sm); s0 = pix_dot<CENTRED>(a, v0, s0); sp = pix_dot<CENTRED>(a, vp, sp);
+                bm = pix_dot<CENTRED>(vm, vm, bm); b0 = pix_dot<CENTRED>(v0, v0, b0); bp = pix_dot<CENTRED>(vp, vp, bp);
+            } else {
+                sm = pix_sad(a, vm, sm); s0 = pix_sad(a, v0, s0); sp = pix_sad(a, vp, sp);
+            }
+        }
+        if constexpr (SSD) {
+            cm += (long long)(int32_t)bm - 2LL * (int32_t)sm;
+            c0 += (long long)(int32_t)b0 - 2LL * (int32_t)s0;
+            cp += (long long)(int32_t)bp - 2LL * (int32_t)sp;
+        } else {
+            cm += sm; c0 += s0; cp += sp;
+        }
+    }
+    const long long num = cm - cp, den = cm - 2 * c0 + cp;
+    if (den > 0) *o = *o + (float)((double)num / (2.0 * (double)den));
+}
+
+hipError_t launch_refine_planes(const Canon &c, Plane a, Plane b, float *out, int out_pitch, hipStream_t s)
+{
+    RefineArgs g{};
+    g.A = a.data; g.B = b.data;
+    g.pitch_a = a.pitch; g.pad_a = a.pad; g.pitch_b = b.pitch; g.pad_b = b.pad;
+    g.wa = c.wa; g.ww = c.ww; g.wh = c.wh; g.wx0 = c.wx0; g.wy0 = c.wy0; g.boff = c.boff;
+    g.d_lo = c.d_lo; g.d_hi = c.d_hi; g.b_lo = c.b_lo; g.b_hi = c.b_hi;
+    g.ox0 = c.ox0; g.ox1 = c.ox1; g.oy0 = c.oy0; g.oy1 = c.oy1;
+    g.ssd = c.ssd; g.centred = march_centred(c); g.mirror = c.mirror;
+    g.out = out; g.out_pitch = out_pitch;
+    dim3 grid(ceil_div(c.ox1 - c.ox0, 256), c.oy1 - c.oy0);
+    if (!c.ssd)
+        hipLaunchKernelGGL((ws_refine_planes_kernel<false, false>), grid, dim3(256), 0, s, g);
+    else if (g.centred)
+        hipLaunchKernelGGL((ws_refine_planes_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((ws_refine_planes_kernel<true, false>), grid, dim3(256), 0, s, g);
+    return hipGetLastError();
 }
 
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s)

@@ -306,7 +306,10 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, s));
     else
         WS_HIP(ctx, launch_generic(ga, s));
-    if (p->subpixel) WS_HIP(ctx, launch_refine(ga, s));
+    if (p->subpixel) {
+        if (march) WS_HIP(ctx, launch_refine_planes(c, ring_a, ring_b, out, out_stride, s));
+        WS_HIP(ctx, launch_refine(ga, s)); // the pixels outside the marching interior (all of them without it)
+    }
     return WS_OK;
 }
 
