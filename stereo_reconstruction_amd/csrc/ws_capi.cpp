@@ -52,6 +52,11 @@ struct ws_context {
     std::string last_kernel;
     int last_threads = 0, last_wgs = 0, last_lds = 0;
     bool var_block_ran = false;
+    // what the last run_search left behind, for the passes that follow it (smoothFactor)
+    bool last_march = false;
+    Canon last_canon{};
+    Plane last_pa{}, last_pb{};
+    int last_skip[4] = {0, 0, 0, 0};
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
 };
 
@@ -218,8 +223,14 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ga.bs_pitch = (R->width + 63) & ~63;
     }
     if ((rc = ensure(ctx, ctx->sel_planes, smooth_planes_bytes(R->width, R->height))) != WS_OK) return rc;
+    const bool on_planes = p->view == WS_VIEW_RIGHT && !p->var_block && ctx->last_march;
+    if (on_planes) {
+        ga.skip_x0 = ctx->last_skip[0]; ga.skip_x1 = ctx->last_skip[1];
+        ga.skip_y0 = ctx->last_skip[2]; ga.skip_y1 = ctx->last_skip[3];
+    }
     WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch,
-                              static_cast<unsigned long long *>(ctx->sel_planes.p), s));
+                              static_cast<unsigned long long *>(ctx->sel_planes.p),
+                              on_planes ? &ctx->last_canon : nullptr, ctx->last_pa, ctx->last_pb, s));
     if (p->subpixel) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
     return WS_OK;
 }
@@ -306,6 +317,12 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, s));
     else
         WS_HIP(ctx, launch_generic(ga, s));
+    ctx->last_march = march;
+    if (march) {
+        ctx->last_canon = c; ctx->last_pa = ring_a; ctx->last_pb = ring_b;
+        ctx->last_skip[0] = ga.skip_x0; ctx->last_skip[1] = ga.skip_x1;
+        ctx->last_skip[2] = ga.skip_y0; ctx->last_skip[3] = ga.skip_y1;
+    }
     if (p->subpixel) {
         if (march) WS_HIP(ctx, launch_refine_planes(c, ring_a, ring_b, out, out_stride, s));
         WS_HIP(ctx, launch_refine(ga, s)); // the pixels outside the marching interior (all of them without it)

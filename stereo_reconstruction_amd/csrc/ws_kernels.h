@@ -95,8 +95,10 @@ int smooth_sel_rows(int rows);
 hipError_t launch_smooth_left(const GenericArgs &g, double s, hipStream_t st);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);
+// canon / pa / pb: the right view's canonical search and packed planes when the marching kernel ran
+// (g's skip rectangle = its interior), else canon == nullptr
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
-                         hipStream_t st);
+                         const Canon *canon, Plane pa, Plane pb, hipStream_t st);
 // nearest-neighbour perspective warp of a float map; minv maps destination -> source pixels
 hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
                        const double minv[9], hipStream_t s);

@@ -26,6 +26,8 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= g.w2 || y >= g.h2) return;
+    // (the marching interior, if any, is prepared on the packed planes: ws_smooth_prepare_planes_kernel)
+    if (x >= g.skip_x0 && x < g.skip_x1 && y >= g.skip_y0 && y < g.skip_y1) return;
     float *o = g.out + (size_t)y * g.out_pitch + x;
     uint8_t code = kSelFixed;
     float val = 0.0f;
@@ -85,6 +87,84 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
     *o = val;
     if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
     sel[(size_t)y * sel_pitch + x] = code;
+}
+
+// The same for the right view's marching interior (complete windows) on the packed, mirrored planes:
+// five v_dot4 (or two v_sad_u8) per window pixel for both costs instead of byte arithmetic.
+struct PreparePlanesArgs {
+    const uint32_t *A;
+    const uint32_t *B;
+    int pitch_a, pad_a, pitch_b, pad_b;
+    int wa, ww, wh, wx0, wy0, boff;
+    int d_hi, b_lo;
+    int ox0, ox1, oy0, oy1;
+    double s;
+    float *out;
+    int out_pitch;
+    uint8_t *sel;
+    int sel_pitch;
+};
+
+template <bool SSD, bool CENTRED>
+__global__ void __launch_bounds__(256) ws_smooth_prepare_planes_kernel(const PreparePlanesArgs g)
+{
+    const int x = g.ox0 + blockIdx.x * blockDim.x + threadIdx.x; // canonical (mirrored) column
+    const int y = g.oy0 + blockIdx.y;
+    if (x >= g.ox1 || y >= g.oy1) return;
+    const int xo = g.wa - 1 - x; // original column
+    float *o = g.out + (size_t)y * g.out_pitch + xo;
+    uint8_t code = kSelFixed;
+    float val = 0.0f;
+    if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] != (CENTRED ? kCentre : 0u)) {
+        const int xb0 = x + g.boff; // target centre of d = 0
+        if (!(g.d_hi >= 0 && xb0 >= g.b_lo)) {
+            val = -(float)xo; // no candidate at all
+        } else if (!(g.d_hi >= 1 && xb0 - 1 >= g.b_lo)) {
+            val = 0.0f; // d = 0 is the only candidate
+        } else {
+            const int d1 = (int)*o;
+            long long c0 = 0, c1 = 0;
+            for (int r = 0; r < g.wh; ++r) {
+                const uint32_t *pa = g.A + (size_t)(y + g.wy0 + r) * g.pitch_a + (x + g.wx0 + g.pad_a);
+                const uint32_t *p0 = g.B + (size_t)(y + g.wy0 + r) * g.pitch_b + (xb0 + g.wx0 + g.pad_b);
+                const uint32_t *p1 = p0 - d1;
+                uint32_t aa = 0, b0 = 0, b1 = 0, ab0 = 0, ab1 = 0;
+                for (int i = 0; i < g.ww; ++i) {
+                    const uint32_t a = pa[i], v0 = p0[i], v1 = p1[i];
+                    if constexpr (SSD) {
+                        aa = pix_dot<CENTRED>(a, a, aa);
+                        b0 = pix_dot<CENTRED>(v0, v0, b0);
+                        b1 = pix_dot<CENTRED>(v1, v1, b1);
+                        ab0 = pix_dot<CENTRED>(a, v0, ab0);
+                        ab1 = pix_dot<CENTRED>(a, v1, ab1);
+                    } else {
+                        ab0 = pix_sad(a, v0, ab0);
+                        ab1 = pix_sad(a, v1, ab1);
+                    }
+                }
+                if constexpr (SSD) { // sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab, row by row in 32 bits
+                    c0 += (long long)(int32_t)aa + (int32_t)b0 - 2LL * (int32_t)ab0;
+                    c1 += (long long)(int32_t)aa + (int32_t)b1 - 2LL * (int32_t)ab1;
+                } else {
+                    c0 += ab0;
+                    c1 += ab1;
+                }
+            }
+            const double area = (double)(g.ww * g.wh);
+            const double e1 = (SSD ? sqrt((double)c1) : (double)c1) / area;
+            double e0 = (SSD ? sqrt((double)c0) : (double)c0) / area;
+            code = 0;
+            if (e1 < e0) code |= 1;
+            e0 *= g.s;
+            if (e1 < e0) code |= 2;
+            e0 *= g.s;
+            if (e1 < e0) code |= 4;
+            val = (float)d1;
+        }
+    }
+    *o = val;
+    if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
+    g.sel[(size_t)y * g.sel_pitch + xo] = code;
 }
 
 // compose two maps {0,1}->{0,1} stored as bit0 = f(0), bit1 = f(1):  (b o a)(v) = b(a(v))
@@ -490,9 +570,25 @@ size_t smooth_planes_bytes(int w, int h)
 }
 
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
-                         hipStream_t st)
+                         const Canon *canon, Plane pa, Plane pb, hipStream_t st)
 {
     dim3 grid(ceil_div(g.w2, 256), g.h2);
+    if (canon) { // right view with a marching interior: its pixels on the planes, the ring on bytes
+        PreparePlanesArgs a{};
+        a.A = pa.data; a.B = pb.data;
+        a.pitch_a = pa.pitch; a.pad_a = pa.pad; a.pitch_b = pb.pitch; a.pad_b = pb.pad;
+        a.wa = canon->wa; a.ww = canon->ww; a.wh = canon->wh; a.wx0 = canon->wx0; a.wy0 = canon->wy0;
+        a.boff = canon->boff; a.d_hi = g.max_d - 1; a.b_lo = canon->b_lo;
+        a.ox0 = canon->ox0; a.ox1 = canon->ox1; a.oy0 = canon->oy0; a.oy1 = canon->oy1;
+        a.s = s; a.out = g.out; a.out_pitch = g.out_pitch; a.sel = sel; a.sel_pitch = sel_pitch;
+        dim3 gi(ceil_div(canon->ox1 - canon->ox0, 256), canon->oy1 - canon->oy0);
+        if (!canon->ssd)
+            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<false, false>), gi, dim3(256), 0, st, a);
+        else if (march_centred(*canon))
+            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<true, true>), gi, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<true, false>), gi, dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
