@@ -100,7 +100,9 @@ struct RingArgs {
 __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g)
 {
     const int lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the pixel is the same for the whole wave: keep it (and every address derived from it) in
+    // scalar registers, so the window of plane A is fetched by scalar loads
+    const long long pix = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     GenericArgs e{}; // only the skip rectangle is used by ring_pixel
     e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
     int x, y;
