@@ -199,7 +199,8 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
         ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
         ga.out = out; ga.out_pitch = out_stride;
-        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, s));
+        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, ctx->last_march ? &ctx->last_canon : nullptr,
+                                       ctx->last_pa, ctx->last_pb, s));
         return WS_OK;
     }
     const bool smooth = q.smooth_factor != 1.0 && q.view != WS_VIEW_LEFT && q.min_disparity == 0;

@@ -333,6 +333,10 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, 
 struct SmoothLeftArgs {
     const uint8_t *L;
     const uint8_t *R;
+    // packed planes of the marching kernel (null: compute the distances from the bytes)
+    const uint32_t *A;
+    const uint32_t *B;
+    int pitch_a, pad_a, pitch_b, pad_b, centred;
     int w1, h1, s1, w2, h2, s2;
     int block_size, max_d, ssd;
     double s;
@@ -345,8 +349,37 @@ __device__ __forceinline__ bool left_candidate_ok(const SmoothLeftArgs &g, int x
     return d >= 1 && d <= g.max_d && x - d >= half && x - d < g.w2 - half;
 }
 
+template <bool CENTRED>
+__device__ __forceinline__ long long left_ssd_planes(const SmoothLeftArgs &g, int x, int y, int d, int half)
+{
+    long long c = 0; // sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab on the dword planes, row by row in 32 bits
+    for (int r = 0; r < g.block_size; ++r) {
+        const uint32_t *pa = g.A + (size_t)(y - half + r) * g.pitch_a + (x - half + g.pad_a);
+        const uint32_t *pb = g.B + (size_t)(y - half + r) * g.pitch_b + (x - d - half + g.pad_b);
+        uint32_t aa = 0, bb = 0, ab = 0;
+        for (int i = 0; i < g.block_size; ++i) {
+            const uint32_t a = pa[i], b = pb[i];
+            aa = pix_dot<CENTRED>(a, a, aa);
+            bb = pix_dot<CENTRED>(b, b, bb);
+            ab = pix_dot<CENTRED>(a, b, ab);
+        }
+        c += (long long)(int32_t)aa + (int32_t)bb - 2LL * (int32_t)ab;
+    }
+    return c;
+}
+
 __device__ __forceinline__ double left_dist(const SmoothLeftArgs &g, int x, int y, int d, int half)
 {
+    if (g.A) {
+        if (g.ssd) return sqrt((double)(g.centred ? left_ssd_planes<true>(g, x, y, d, half) : left_ssd_planes<false>(g, x, y, d, half)));
+        uint32_t acc = 0;
+        for (int r = 0; r < g.block_size; ++r) {
+            const uint32_t *pa = g.A + (size_t)(y - half + r) * g.pitch_a + (x - half + g.pad_a);
+            const uint32_t *pb = g.B + (size_t)(y - half + r) * g.pitch_b + (x - d - half + g.pad_b);
+            for (int i = 0; i < g.block_size; ++i) acc = pix_sad(pa[i], pb[i], acc);
+        }
+        return (double)acc;
+    }
     const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
     const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (x - d - half);
     const uint32_t c = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
@@ -460,9 +493,14 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftAr
     }
 }
 
-hipError_t launch_smooth_left(const GenericArgs &g, double s, hipStream_t st)
+hipError_t launch_smooth_left(const GenericArgs &g, double s, const Canon *canon, Plane pa, Plane pb, hipStream_t st)
 {
     SmoothLeftArgs a{};
+    if (canon) { // the marching kernel ran: its planes are the two images, one dword per pixel
+        a.A = pa.data; a.B = pb.data;
+        a.pitch_a = pa.pitch; a.pad_a = pa.pad; a.pitch_b = pb.pitch; a.pad_b = pb.pad;
+        a.centred = march_centred(*canon);
+    }
     a.L = g.L; a.R = g.R; a.w1 = g.w1; a.h1 = g.h1; a.s1 = g.s1; a.w2 = g.w2; a.h2 = g.h2; a.s2 = g.s2;
     a.block_size = g.block_size; a.max_d = g.max_d; a.ssd = g.ssd; a.s = s;
     a.out = g.out; a.out_pitch = g.out_pitch;
