@@ -273,6 +273,39 @@ def test_randomised_differential(wslib, gpu_ctx, oracle, seed):
     assert np.array_equal(got, want), (view, bs, mind, maxd, cost, smooth, left.shape, right.shape, levels)
 
 
+def test_strided_buffers_and_extreme_arguments(wslib, gpu_ctx, oracle):
+    """Row strides larger than the row (cv::Mat ROIs), padded output, absurd disparity ranges."""
+    import ctypes
+    import torch
+    big_l, big_r, _ = make_pair(260, 60, 40, seed=71)
+    left, right = big_l[5:55, 10:230], big_r[5:55, 10:230]          # non-contiguous views: stride 780 > 3 * 220
+    assert not left.flags["C_CONTIGUOUS"]
+    want = oracle.block_left(np.ascontiguousarray(left), np.ascontiguousarray(right), 7, 0, 40)
+    p = wslib.make_params(wslib.VIEW_LEFT, 7, 0, 40)
+    lib = wslib.load_library()
+    Li = wslib._Image(left.ctypes.data, 220, 50, left.strides[0])
+    Ri = wslib._Image(right.ctypes.data, 220, 50, right.strides[0])
+    out = np.full((50, 256), -5.0, dtype=np.float64)                 # out_stride 256 > width 220
+    rc = lib.ws_search_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), out.ctypes.data, 256, 1)
+    assert rc == 0 and np.array_equal(out[:, :220], want) and (out[:, 220:] == -5.0).all()
+    # the same through the device entry point with strided device tensors
+    tl, tr = torch.from_numpy(big_l).cuda()[5:55, 10:230], torch.from_numpy(big_r).cuda()[5:55, 10:230]
+    to = torch.full((50, 256), -5.0, dtype=torch.float32, device="cuda")
+    gpu_ctx.search_device(p, tl, tr, to[:, :220], None)
+    torch.cuda.synchronize()
+    assert np.array_equal(to.cpu().numpy()[:, :220].astype(np.float64), want) and bool((to[:, 220:] == -5.0).all())
+    # a disparity range far wider than the image, and the largest window the ABI accepts
+    l2, r2 = np.ascontiguousarray(left), np.ascontiguousarray(right)
+    for view in ("left", "right"):
+        got = run(wslib, gpu_ctx, view, l2, r2, 5, 0, 100000, "sad")
+        assert np.array_equal(got, ref(oracle, view, l2, r2, 5, 0, 100000, "sad"))
+    got = run(wslib, gpu_ctx, "left", l2, r2, 63, 0, 30, "ssd")
+    assert np.array_equal(got, ref(oracle, "left", l2, r2, 63, 0, 30, "ssd"))
+    with pytest.raises(wslib.WsError) as e:
+        run(wslib, gpu_ctx, "left", l2, r2, 65, 0, 30, "ssd")
+    assert e.value.code == -1
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
