@@ -46,7 +46,7 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, keys, bs_plane, max_block, sel, sel_planes, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, keys, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
@@ -107,10 +107,6 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
     if (p->view != WS_VIEW_LINEAR && (p->block_size < 1 || p->block_size > 63))
         return fail(ctx, WS_ERR_ARG, "blockSize %d outside [1,63]", p->block_size);
     if (p->view == WS_VIEW_LINEAR && p->linear_range < 1) return fail(ctx, WS_ERR_ARG, "linear_range < 1");
-    if (p->view == WS_VIEW_LEFT && (p->smooth_factor > 1.0 || p->smooth_factor < 0.0))
-        return fail(ctx, WS_ERR_UNSUPPORTED,
-                    "smoothFactor %.3f in the left view: the device handles 0 <= smoothFactor <= 1 "
-                    "(BlockSearch.cpp:68-73)", p->smooth_factor);
     if (p->view == WS_VIEW_LEFT && p->smooth_factor != 1.0 && L->width > 4096)
         return fail(ctx, WS_ERR_UNSUPPORTED, "smoothFactor != 1 in the left view: images up to 4096 columns");
     if (!(p->smooth_factor == p->smooth_factor)) return fail(ctx, WS_ERR_ARG, "smoothFactor is NaN");
@@ -199,7 +195,12 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
         ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
         ga.out = out; ga.out_pitch = out_stride;
-        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, ctx->last_march ? &ctx->last_canon : nullptr,
+        uint32_t *top3 = nullptr;
+        if (p->smooth_factor > 1.0 || p->smooth_factor < 0.0) { // the three best candidates per pixel
+            if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
+            top3 = static_cast<uint32_t *>(ctx->top3.p);
+        }
+        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march ? &ctx->last_canon : nullptr,
                                        ctx->last_pa, ctx->last_pb, s));
         return WS_OK;
     }
@@ -399,7 +400,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);

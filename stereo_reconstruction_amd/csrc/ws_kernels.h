@@ -92,7 +92,10 @@ hipError_t launch_refine_planes(const Canon &c, Plane a, Plane b, float *out, in
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
 // smoothFactor in [0,1], left view: g.out holds the smoothFactor-1 result on entry
-hipError_t launch_smooth_left(const GenericArgs &g, double s, const Canon *canon, Plane pa, Plane pb, hipStream_t st);
+// top3: smooth_left_top_bytes(w1, h1) of scratch, only read / written when s is outside [0,1]
+hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
+                              hipStream_t st);
+size_t smooth_left_top_bytes(int w, int h);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);
 // canon / pa / pb: the right view's canonical search and packed planes when the marching kernel ran

@@ -493,7 +493,185 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftAr
     }
 }
 
-hipError_t launch_smooth_left(const GenericArgs &g, double s, const Canon *canon, Plane pa, Plane pb, hipStream_t st)
+
+// ---- any other smoothFactor (s > 1, s < 0) in the left view ------------------------------------
+// A factor that can make a candidate DEARER breaks the {d1, up, left} argument above, but only two
+// candidates (the neighbours' values) are ever touched, so the winner is the upper / left
+// neighbour's value or one of the THREE best untouched candidates in the reference's own order
+// (cost ascending, then d descending).  ws_left_top3_kernel keeps those three per pixel (one
+// thread per pixel, d descending like BlockSearch.cpp:53, strict '<'); the raster pass below is
+// the same row walk / fixed-point iteration as above with F_x taken over {t0, t1, t2, up, left}.
+__device__ __forceinline__ uint32_t left_cost_int(const SmoothLeftArgs &g, int x, int y, int d, int half)
+{
+    if (g.A) {
+        if (g.ssd) return (uint32_t)(g.centred ? left_ssd_planes<true>(g, x, y, d, half) : left_ssd_planes<false>(g, x, y, d, half));
+        uint32_t acc = 0;
+        for (int r = 0; r < g.block_size; ++r) {
+            const uint32_t *pa = g.A + (size_t)(y - half + r) * g.pitch_a + (x - half + g.pad_a);
+            const uint32_t *pb = g.B + (size_t)(y - half + r) * g.pitch_b + (x - d - half + g.pad_b);
+            for (int i = 0; i < g.block_size; ++i) acc = pix_sad(pa[i], pb[i], acc);
+        }
+        return acc;
+    }
+    const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+    const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (x - d - half);
+    return window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+}
+
+constexpr uint32_t kTopNone = 0xffffffffu; // above any window cost (63 * 63 * 3 * 255^2 < 2^30)
+
+__global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
+{
+    const int half = (g.block_size - 1) / 2;
+    const int x = half + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = half + blockIdx.y;
+    if (x >= g.w1 - half) return;
+    uint32_t c0 = kTopNone, c1 = kTopNone, c2 = kTopNone;
+    int d0 = 0, d1 = 0, d2 = 0;
+    if (!black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+        const int d_hi = min(g.max_d, x - half);
+        const int d_lo = max(1, x - (g.w2 - half) + 1);
+        for (int d = d_hi; d >= d_lo; --d) {
+            const uint32_t c = left_cost_int(g, x, y, d, half);
+            if (c < c2) { // strict: an equal cost met later (smaller d) stays behind
+                if (c < c1) {
+                    c2 = c1; d2 = d1;
+                    if (c < c0) { c1 = c0; d1 = d0; c0 = c; d0 = d; }
+                    else { c1 = c; d1 = d; }
+                } else { c2 = c; d2 = d; }
+            }
+        }
+    }
+    uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
+    reinterpret_cast<uint2 *>(t)[0] = make_uint2(c0, (uint32_t)d0);
+    reinterpret_cast<uint2 *>(t)[1] = make_uint2(c1, (uint32_t)d1);
+    reinterpret_cast<uint2 *>(t)[2] = make_uint2(c2, (uint32_t)d2);
+}
+
+// the reference's running minimum: 'min' starts at DBL_MAX with no winner, d descending, strict '<'
+struct LeftBest {
+    double dist;
+    int d;
+    __device__ __forceinline__ void consider(double m, int cd)
+    {
+        if (m < dist || (m == dist && d >= 0 && cd > d)) { dist = m; d = cd; }
+    }
+};
+
+constexpr int kSmoothLeftGenPer = 4;
+
+__global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
+                                                                     int top_pitch)
+{
+    extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
+    __shared__ int changed;
+    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (g.block_size - 1) / 2;
+    const int height = min(g.h1, g.h2);
+    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f;
+    if (half > 0)
+        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
+    __syncthreads();
+    for (int y = half; y < height - half; ++y) {
+        float *orow = g.out + (size_t)y * g.out_pitch;
+        int td[kSmoothLeftGenPer][3], du[kSmoothLeftGenPer], lastl[kSmoothLeftGenPer];
+        double tm[kSmoothLeftGenPer][3], uu[kSmoothLeftGenPer], ul[kSmoothLeftGenPer];
+        bool act[kSmoothLeftGenPer];
+#pragma unroll
+        for (int k = 0; k < kSmoothLeftGenPer; ++k) {
+            const int x = tid + k * nt;
+            act[k] = false;
+            du[k] = 0; lastl[k] = -1; uu[k] = ul[k] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { td[k][i] = 0; tm[k][i] = 0.0; }
+            if (x < g.w1) {
+                cur[x] = orow[x]; // border zeros, black zeros and "no candidate" values stay as the search left them
+                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+                    const uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
+                    const int up = (int)prev[x];
+                    const bool up_ok = y >= 1 && (float)up == prev[x] && left_candidate_ok(g, x, up, half);
+                    bool up_listed = false;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const uint2 e = reinterpret_cast<const uint2 *>(t)[i];
+                        if (e.x == kTopNone) continue;
+                        act[k] = true;
+                        td[k][i] = (int)e.y;
+                        double m = g.ssd ? sqrt((double)e.x) : (double)e.x;
+                        if (up_ok && up == (int)e.y) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
+                        tm[k][i] = m;
+                    }
+                    if (act[k] && up_ok && !up_listed) {
+                        du[k] = up;
+                        uu[k] = left_dist(g, x, y, up, half) * g.s;
+                    }
+                    if (act[k]) { // the guess without a left neighbour
+                        LeftBest b{1.7976931348623157e308, -1};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            if (td[k][i] > 0) b.consider(tm[k][i], td[k][i]);
+                        if (du[k] > 0) b.consider(uu[k], du[k]);
+                        cur[x] = b.d >= 0 ? (float)b.d : (float)x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = 0; it < g.w1 + 1; ++it) {
+            if (tid == 0) changed = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSmoothLeftGenPer; ++k) {
+                const int x = tid + k * nt;
+                if (x >= g.w1) continue;
+                float res = cur[x];
+                if (act[k]) {
+                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
+                    const int l = (int)lf;
+                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
+                    LeftBest b{1.7976931348623157e308, -1};
+                    bool l_listed = false;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (td[k][i] <= 0) continue;
+                        double m = tm[k][i];
+                        if (l_ok && l == td[k][i]) { m *= g.s; l_listed = true; } // the left factor second (:71-73)
+                        b.consider(m, td[k][i]);
+                    }
+                    if (du[k] > 0) {
+                        double m = uu[k];
+                        if (l_ok && l == du[k]) { m *= g.s; l_listed = true; }
+                        b.consider(m, du[k]);
+                    }
+                    if (l_ok && !l_listed) {
+                        if (lastl[k] != l) {
+                            ul[k] = left_dist(g, x, y, l, half);
+                            lastl[k] = l;
+                        }
+                        b.consider(ul[k] * g.s, l);
+                    }
+                    res = b.d >= 0 ? (float)b.d : (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
+                }
+                nxt[x] = res;
+                if (res != cur[x]) changed = 1;
+            }
+            __syncthreads();
+            float *t = cur; cur = nxt; nxt = t;
+            const int any = changed;
+            __syncthreads();
+            if (!any) break;
+        }
+        for (int x = tid; x < g.w1; x += nt) orow[x] = cur[x];
+        __syncthreads();
+        { float *t = prev; prev = cur; cur = t; }
+    }
+}
+
+size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * 6 * sizeof(uint32_t); }
+
+hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
+                              hipStream_t st)
 {
     SmoothLeftArgs a{};
     if (canon) { // the marching kernel ran: its planes are the two images, one dword per pixel
@@ -505,7 +683,16 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, const Canon *canon
     a.block_size = g.block_size; a.max_d = g.max_d; a.ssd = g.ssd; a.s = s;
     a.out = g.out; a.out_pitch = g.out_pitch;
     if (g.w1 > kSmoothLeftPer * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a);
+    if (s >= 0.0 && s <= 1.0) {
+        hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a);
+        return hipGetLastError();
+    }
+    if (!top3 || g.w1 > kSmoothLeftGenPer * 1024) return hipErrorInvalidValue;
+    const int half = (g.block_size - 1) / 2;
+    const int iw = g.w1 - 2 * half, ih = std::min(g.h1, g.h2) - 2 * half;
+    if (iw <= 0 || ih <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
+    hipLaunchKernelGGL(ws_smooth_left_general_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a, top3, g.w1);
     return hipGetLastError();
 }
 

@@ -149,11 +149,12 @@ def test_smooth_factor_right_view_and_linear(wslib, gpu_ctx, oracle, smooth, lev
     assert np.array_equal(got, oracle.linear(left, right, smooth=smooth))
 
 
-@pytest.mark.parametrize("smooth", [0.9, 0.5, 0.0])
+@pytest.mark.parametrize("smooth", [0.9, 0.5, 0.0, 1.3, 4.0, -0.5, -2.0, float("inf")])
 @pytest.mark.parametrize("levels", [256, 3, 2])
 def test_smooth_factor_left_view(wslib, gpu_ctx, oracle, smooth, levels):
     """Left view: the factor reaches whatever d the upper / left neighbour holds (BlockSearch.cpp:68-73),
-    a true raster-order dependency; the device iterates each row to its fixed point."""
+    a true raster-order dependency; the device iterates each row to its fixed point.  Factors outside
+    [0,1] (a penalty, a sign flip) go through the three-best-candidates pass."""
     if levels == 256:
         left, right, _ = make_pair(300, 48, 40, seed=41)
     else:
@@ -263,10 +264,11 @@ def test_randomised_differential(wslib, gpu_ctx, oracle, seed):
     maxd = int(rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 100, 200, 300, 513]))
     mind = int(rng.choice([0, 0, 1, 5])) if view == "right" else 0
     cost = "ssd" if rng.random() < 0.5 else "sad"
-    smooth = float(rng.choice([1.0, 1.0, 0.9, 0.3])) if view == "right" else 1.0
+    smooth = float(rng.choice([1.0, 1.0, 0.9, 0.3] if view == "right" else [1.0, 1.0, 0.9, 1.6, -0.4]))
     b = wslib.BlockSearch(left, right, bs, mind, maxd, cost=cost, context=gpu_ctx)
     if view == "left":
-        got, want = b.computeDisparityMapLeft(1.0), oracle.block_left(left, right, bs, mind, maxd, cost=cost, threads=8)
+        got = b.computeDisparityMapLeft(smooth)
+        want = oracle.block_left(left, right, bs, mind, maxd, smooth=smooth, cost=cost, threads=8)
     else:
         got = b.computeDisparityMapRight(smooth)
         want = oracle.block_right(left, right, bs, mind, maxd, smooth=smooth, cost=cost, threads=8)
@@ -312,8 +314,8 @@ def test_errors_are_reported_not_computed(wslib, gpu_ctx):
         run(wslib, gpu_ctx, "left", left, right, 6, 0, 16, "ssd")
     assert e.value.code == -2                       # even blockSize: the reference throws
     with pytest.raises(wslib.WsError) as e:
-        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapLeft(1.5)
-    assert e.value.code == -3                       # left view: smoothFactor > 1 is not on the device
+        wslib.BlockSearch(left, right, 7, 0, 16, context=gpu_ctx).computeDisparityMapLeft(float("nan"))
+    assert e.value.code == -1
     with pytest.raises(wslib.WsError) as e:
         wslib.BlockSearch(left, right, 7, 0, 16, subpixel=True, context=gpu_ctx).computeDisparityMapRight(0.9)
     assert e.value.code == -3                       # the sub-pixel extension needs smoothFactor 1
