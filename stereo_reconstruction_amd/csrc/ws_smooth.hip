@@ -368,139 +368,38 @@ __device__ __forceinline__ long long left_ssd_planes(const SmoothLeftArgs &g, in
     return c;
 }
 
-__device__ __forceinline__ double left_dist(const SmoothLeftArgs &g, int x, int y, int d, int half)
+// One window column: pixels (xc, y-half .. y+half) of the left image against (xc - d, ..) of the
+// right one.  The distance of a fixed d at consecutive x is a sliding sum of these.
+__device__ __forceinline__ uint32_t left_col_cost(const SmoothLeftArgs &g, int xc, int y, int d, int half)
 {
     if (g.A) {
-        if (g.ssd) return sqrt((double)(g.centred ? left_ssd_planes<true>(g, x, y, d, half) : left_ssd_planes<false>(g, x, y, d, half)));
-        uint32_t acc = 0;
-        for (int r = 0; r < g.block_size; ++r) {
-            const uint32_t *pa = g.A + (size_t)(y - half + r) * g.pitch_a + (x - half + g.pad_a);
-            const uint32_t *pb = g.B + (size_t)(y - half + r) * g.pitch_b + (x - d - half + g.pad_b);
-            for (int i = 0; i < g.block_size; ++i) acc = pix_sad(pa[i], pb[i], acc);
+        const uint32_t *pa = g.A + (size_t)(y - half) * g.pitch_a + (xc + g.pad_a);
+        const uint32_t *pb = g.B + (size_t)(y - half) * g.pitch_b + (xc - d + g.pad_b);
+        if (!g.ssd) {
+            uint32_t acc = 0;
+            for (int r = 0; r < g.block_size; ++r) acc = pix_sad(pa[(size_t)r * g.pitch_a], pb[(size_t)r * g.pitch_b], acc);
+            return acc;
         }
-        return (double)acc;
-    }
-    const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
-    const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (x - d - half);
-    const uint32_t c = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
-    return g.ssd ? sqrt((double)c) : (double)c;
-}
-
-// candidate (dist, d) beats (bd, bdist) in the reference's iteration (d descending, strict <)
-__device__ __forceinline__ bool left_better(double dist, int d, double bdist, int bd)
-{
-    return dist < bdist || (dist == bdist && d > bd);
-}
-
-constexpr int kSmoothLeftPer = 4; // columns per thread: images up to 4096 wide
-
-__global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftArgs g)
-{
-    extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
-    __shared__ int changed;
-    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int half = (g.block_size - 1) / 2;
-    const int height = min(g.h1, g.h2);
-    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f; // row above the first interior row: border zeros
-    if (half > 0) // (for half == 0 the first row has no upper neighbour at all: zeros never match d >= 1)
-        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
-    __syncthreads();
-    for (int y = half; y < height - half; ++y) {
-        float *orow = g.out + (size_t)y * g.out_pitch;
-        // per column: the fixed ingredients of F_x
-        int d1[kSmoothLeftPer], du[kSmoothLeftPer], lastl[kSmoothLeftPer];
-        double u1[kSmoothLeftPer], uu[kSmoothLeftPer], ul[kSmoothLeftPer];
-        bool act[kSmoothLeftPer];
-#pragma unroll
-        for (int k = 0; k < kSmoothLeftPer; ++k) {
-            const int x = tid + k * nt;
-            act[k] = false;
-            d1[k] = du[k] = 0; lastl[k] = -1;
-            u1[k] = uu[k] = ul[k] = 0.0;
-            if (x < g.w1) {
-                const float v = orow[x];
-                cur[x] = v;
-                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
-                    const int d = (int)v;
-                    if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, value x stays
-                        act[k] = true;
-                        d1[k] = d;
-                        u1[k] = left_dist(g, x, y, d, half);
-                        const int up = (int)prev[x];
-                        const bool up_int = (float)up == prev[x];
-                        if (y >= 1 && up_int && up != d && left_candidate_ok(g, x, up, half)) {
-                            du[k] = up;
-                            uu[k] = left_dist(g, x, y, up, half) * g.s;
-                        } else if (y >= 1 && up_int && up == d) {
-                            du[k] = -1; // d1 itself is the upper neighbour's value
-                            u1[k] *= g.s;
-                        }
-                        // the guess without a left neighbour
-                        float gx = (float)d;
-                        if (du[k] > 0 && left_better(uu[k], du[k], u1[k], d)) gx = (float)du[k];
-                        cur[x] = gx;
-                    }
-                }
+        uint32_t aa = 0, bb = 0, ab = 0;
+        if (g.centred) {
+            for (int r = 0; r < g.block_size; ++r) {
+                const uint32_t a = pa[(size_t)r * g.pitch_a], b = pb[(size_t)r * g.pitch_b];
+                aa = pix_dot<true>(a, a, aa); bb = pix_dot<true>(b, b, bb); ab = pix_dot<true>(a, b, ab);
+            }
+        } else {
+            for (int r = 0; r < g.block_size; ++r) {
+                const uint32_t a = pa[(size_t)r * g.pitch_a], b = pb[(size_t)r * g.pitch_b];
+                aa = pix_dot<false>(a, a, aa); bb = pix_dot<false>(b, b, bb); ab = pix_dot<false>(a, b, ab);
             }
         }
-        __syncthreads();
-        for (int it = 0; it < g.w1 + 1; ++it) {
-            if (tid == 0) changed = 0;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kSmoothLeftPer; ++k) {
-                const int x = tid + k * nt;
-                if (x >= g.w1) continue;
-                float res = cur[x];
-                if (act[k]) {
-                    // start from d1 (its upper-neighbour factor already in u1), then up, then left
-                    double bdist = u1[k];
-                    int bd = d1[k];
-                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
-                    const int l = (int)lf;
-                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
-                    if (l_ok && l == d1[k]) bdist = bdist * g.s; // the left factor comes second (BlockSearch.cpp:71-73)
-                    if (du[k] > 0) {
-                        double e = uu[k];
-                        if (l_ok && l == du[k]) e = e * g.s;
-                        if (left_better(e, du[k], bdist, bd)) { bdist = e; bd = du[k]; }
-                    }
-                    if (l_ok && l != d1[k] && l != du[k]) {
-                        if (lastl[k] != l) { // distance at the left neighbour's value: cached per column
-                            ul[k] = left_dist(g, x, y, l, half);
-                            lastl[k] = l;
-                        }
-                        const double e = ul[k] * g.s;
-                        if (left_better(e, l, bdist, bd)) { bdist = e; bd = l; }
-                    }
-                    res = (float)bd;
-                }
-                nxt[x] = res;
-                if (res != cur[x]) changed = 1;
-            }
-            __syncthreads();
-            float *t = cur; cur = nxt; nxt = t;
-            const int any = changed;
-            __syncthreads();
-            if (!any) break;
-        }
-        for (int x = tid; x < g.w1; x += nt) {
-            orow[x] = cur[x];
-        }
-        __syncthreads();
-        { float *t = prev; prev = cur; cur = t; }
+        return (uint32_t)((int32_t)aa + (int32_t)bb - 2 * (int32_t)ab);
     }
+    const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * xc;
+    const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (xc - d);
+    return window_cost(lw, g.s1, rw, g.s2, 1, g.block_size, g.ssd);
 }
 
-
-// ---- any other smoothFactor (s > 1, s < 0) in the left view ------------------------------------
-// A factor that can make a candidate DEARER breaks the {d1, up, left} argument above, but only two
-// candidates (the neighbours' values) are ever touched, so the winner is the upper / left
-// neighbour's value or one of the THREE best untouched candidates in the reference's own order
-// (cost ascending, then d descending).  ws_left_top3_kernel keeps those three per pixel (one
-// thread per pixel, d descending like BlockSearch.cpp:53, strict '<'); the raster pass below is
-// the same row walk / fixed-point iteration as above with F_x taken over {t0, t1, t2, up, left}.
+// the whole window, row by row
 __device__ __forceinline__ uint32_t left_cost_int(const SmoothLeftArgs &g, int x, int y, int d, int half)
 {
     if (g.A) {
@@ -518,6 +417,150 @@ __device__ __forceinline__ uint32_t left_cost_int(const SmoothLeftArgs &g, int x
     return window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
 }
 
+__device__ __forceinline__ double left_dist_of(const SmoothLeftArgs &g, uint32_t c)
+{
+    return g.ssd ? sqrt((double)c) : (double)c; // cv::norm(NORM_L2) of the window (BlockSearch.cpp:66)
+}
+
+__device__ __forceinline__ double left_dist(const SmoothLeftArgs &g, int x, int y, int d, int half)
+{
+    return left_dist_of(g, left_cost_int(g, x, y, d, half));
+}
+
+// candidate (dist, d) beats (bd, bdist) in the reference's iteration (d descending, strict <)
+__device__ __forceinline__ bool left_better(double dist, int d, double bdist, int bd)
+{
+    return dist < bdist || (dist == bdist && d > bd);
+}
+
+constexpr int kSmoothLeftPer = 4; // columns per thread: images up to 4096 wide
+
+constexpr uint32_t kCostUnknown = 0xffffffffu; // published beside a value whose window distance is not known
+
+__global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftArgs g)
+{
+    // [3][w1] floats: previous row, current guess, next guess; [2][w1] integer window costs of the
+    // guesses (cost of (x, cur[x])): x+1 slides them by one column instead of summing a whole window
+    extern __shared__ float sl_rows[];
+    __shared__ int changed[3];
+    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
+    uint32_t *ccur = reinterpret_cast<uint32_t *>(sl_rows + 3 * g.w1), *cnxt = ccur + g.w1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (g.block_size - 1) / 2;
+    const int height = min(g.h1, g.h2);
+    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f; // row above the first interior row: border zeros
+    if (half > 0) // (for half == 0 the first row has no upper neighbour at all: zeros never match d >= 1)
+        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
+    __syncthreads();
+    for (int y = half; y < height - half; ++y) {
+        float *orow = g.out + (size_t)y * g.out_pitch;
+        // per column: the fixed ingredients of F_x
+        int d1[kSmoothLeftPer], du[kSmoothLeftPer], lastl[kSmoothLeftPer];
+        uint32_t c1[kSmoothLeftPer], cu[kSmoothLeftPer], cl[kSmoothLeftPer];
+        double u1[kSmoothLeftPer], uu[kSmoothLeftPer];
+        bool act[kSmoothLeftPer];
+#pragma unroll
+        for (int k = 0; k < kSmoothLeftPer; ++k) {
+            const int x = tid + k * nt;
+            act[k] = false;
+            d1[k] = du[k] = 0; lastl[k] = -1;
+            c1[k] = cu[k] = cl[k] = 0;
+            u1[k] = uu[k] = 0.0;
+            if (x < g.w1) {
+                const float v = orow[x];
+                cur[x] = v;
+                ccur[x] = kCostUnknown;
+                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+                    const int d = (int)v;
+                    if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, value x stays
+                        act[k] = true;
+                        d1[k] = d;
+                        c1[k] = left_cost_int(g, x, y, d, half);
+                        u1[k] = left_dist_of(g, c1[k]);
+                        const int up = (int)prev[x];
+                        const bool up_int = (float)up == prev[x];
+                        if (y >= 1 && up_int && up != d && left_candidate_ok(g, x, up, half)) {
+                            du[k] = up;
+                            cu[k] = left_cost_int(g, x, y, up, half);
+                            uu[k] = left_dist_of(g, cu[k]) * g.s;
+                        } else if (y >= 1 && up_int && up == d) {
+                            du[k] = -1; // d1 itself is the upper neighbour's value
+                            u1[k] *= g.s;
+                        }
+                        // the guess without a left neighbour
+                        const bool take_up = du[k] > 0 && left_better(uu[k], du[k], u1[k], d);
+                        cur[x] = take_up ? (float)du[k] : (float)d;
+                        ccur[x] = take_up ? cu[k] : c1[k];
+                    }
+                }
+            }
+        }
+        if (tid < 3) changed[tid] = 0;
+        __syncthreads();
+        // one barrier per iteration: guesses are double-buffered and the "changed" flag rotates over
+        // three slots (slot it+2 is cleared while slot it is read and slot it+1 may already be set)
+        for (int it = 0; it < g.w1 + 1; ++it) {
+            const int slot = it % 3;
+#pragma unroll
+            for (int k = 0; k < kSmoothLeftPer; ++k) {
+                const int x = tid + k * nt;
+                if (x >= g.w1) continue;
+                float res = cur[x];
+                uint32_t rc = ccur[x];
+                if (act[k]) {
+                    // start from d1 (its upper-neighbour factor already in u1), then up, then left
+                    double bdist = u1[k];
+                    int bd = d1[k];
+                    rc = c1[k];
+                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
+                    const int l = (int)lf;
+                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
+                    if (l_ok && l == d1[k]) bdist = bdist * g.s; // the left factor comes second (BlockSearch.cpp:71-73)
+                    if (du[k] > 0) {
+                        double e = uu[k];
+                        if (l_ok && l == du[k]) e = e * g.s;
+                        if (left_better(e, du[k], bdist, bd)) { bdist = e; bd = du[k]; rc = cu[k]; }
+                    }
+                    if (l_ok && l != d1[k] && l != du[k]) {
+                        if (lastl[k] != l) { // distance at the left neighbour's value: cached per column
+                            const uint32_t cprev = ccur[x - 1]; // the window of (x-1, l), one column to the left
+                            if (cprev != kCostUnknown && g.block_size > 2)
+                                cl[k] = cprev + left_col_cost(g, x + half, y, l, half) - left_col_cost(g, x - 1 - half, y, l, half);
+                            else
+                                cl[k] = left_cost_int(g, x, y, l, half);
+                            lastl[k] = l;
+                        }
+                        const double e = left_dist_of(g, cl[k]) * g.s;
+                        if (left_better(e, l, bdist, bd)) { bdist = e; bd = l; rc = cl[k]; }
+                    }
+                    res = (float)bd;
+                }
+                nxt[x] = res;
+                cnxt[x] = rc;
+                if (res != cur[x]) changed[slot] = 1;
+            }
+            __syncthreads();
+            { float *t = cur; cur = nxt; nxt = t; }
+            { uint32_t *t = ccur; ccur = cnxt; cnxt = t; }
+            const int any = changed[slot];
+            if (tid == 0) changed[(it + 2) % 3] = 0;
+            if (!any) break;
+        }
+        for (int x = tid; x < g.w1; x += nt) {
+            orow[x] = cur[x];
+        }
+        __syncthreads();
+        { float *t = prev; prev = cur; cur = t; }
+    }
+}
+
+// ---- any other smoothFactor (s > 1, s < 0) in the left view ------------------------------------
+// A factor that can make a candidate DEARER breaks the {d1, up, left} argument above, but only two
+// candidates (the neighbours' values) are ever touched, so the winner is the upper / left
+// neighbour's value or one of the THREE best untouched candidates in the reference's own order
+// (cost ascending, then d descending).  ws_left_top3_kernel keeps those three per pixel (one
+// thread per pixel, d descending like BlockSearch.cpp:53, strict '<'); the raster pass below is
+// the same row walk / fixed-point iteration as above with F_x taken over {t0, t1, t2, up, left}.
 constexpr uint32_t kTopNone = 0xffffffffu; // above any window cost (63 * 63 * 3 * 255^2 < 2^30)
 
 __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
@@ -564,7 +607,7 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const Smoo
                                                                      int top_pitch)
 {
     extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
-    __shared__ int changed;
+    __shared__ int changed[3];
     float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int half = (g.block_size - 1) / 2;
@@ -617,10 +660,12 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const Smoo
                 }
             }
         }
+        if (tid < 3) changed[tid] = 0;
         __syncthreads();
+        // one barrier per iteration: guesses are double-buffered and the "changed" flag rotates over
+        // three slots (slot it+2 is cleared while slot it is read and slot it+1 may already be set)
         for (int it = 0; it < g.w1 + 1; ++it) {
-            if (tid == 0) changed = 0;
-            __syncthreads();
+            const int slot = it % 3;
 #pragma unroll
             for (int k = 0; k < kSmoothLeftGenPer; ++k) {
                 const int x = tid + k * nt;
@@ -654,12 +699,12 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const Smoo
                     res = b.d >= 0 ? (float)b.d : (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
                 }
                 nxt[x] = res;
-                if (res != cur[x]) changed = 1;
+                if (res != cur[x]) changed[slot] = 1;
             }
             __syncthreads();
             float *t = cur; cur = nxt; nxt = t;
-            const int any = changed;
-            __syncthreads();
+            const int any = changed[slot];
+            if (tid == 0) changed[(it + 2) % 3] = 0;
             if (!any) break;
         }
         for (int x = tid; x < g.w1; x += nt) orow[x] = cur[x];
@@ -684,7 +729,13 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     a.out = g.out; a.out_pitch = g.out_pitch;
     if (g.w1 > kSmoothLeftPer * 1024) return hipErrorInvalidValue;
     if (s >= 0.0 && s <= 1.0) {
-        hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a);
+        const size_t lds = (size_t)g.w1 * 20; // 3 float rows + 2 rows of integer costs
+        if (lds > 48 * 1024) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(ws_smooth_left_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+        }
+        hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), lds, st, a);
         return hipGetLastError();
     }
     if (!top3 || g.w1 > kSmoothLeftGenPer * 1024) return hipErrorInvalidValue;
