@@ -612,6 +612,7 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const Smoo
     const int tid = threadIdx.x, nt = blockDim.x;
     const int half = (g.block_size - 1) / 2;
     const int height = min(g.h1, g.h2);
+    const bool other_can_win = !(g.s >= 1.0);
     for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f;
     if (half > 0)
         for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
@@ -689,7 +690,9 @@ __global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const Smoo
                         if (l_ok && l == du[k]) { m *= g.s; l_listed = true; }
                         b.consider(m, du[k]);
                     }
-                    if (l_ok && !l_listed) {
+                    // (for s >= 1 an unlisted left value cannot win: two of t0..t2 are untouched, rank
+                    // before it, and its own distance only grows -- so its window is never summed)
+                    if (l_ok && !l_listed && other_can_win) {
                         if (lastl[k] != l) {
                             ul[k] = left_dist(g, x, y, l, half);
                             lastl[k] = l;
