@@ -287,9 +287,16 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ring_b = pb;
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
-        WS_HIP(ctx, launch_pack(ia->data, ia->width, ia->height, ia->stride, pa, ib->data, ib->width,
-                                ib->height, ib->stride, pb, c.mirror, march_centred(c), s));
-        if (c.ssd) WS_HIP(ctx, launch_bias(c, m, pb, pbi, s));
+        if (c.mirror) {
+            ga.skip_x0 = c.wa - c.ox1; ga.skip_x1 = c.wa - c.ox0;
+        } else {
+            ga.skip_x0 = c.ox0; ga.skip_x1 = c.ox1;
+        }
+        ga.skip_y0 = c.oy0; ga.skip_y1 = c.oy1;
+        // left view: the pixels outside the interior only need the images, they ride along here;
+        // the right view's ring runs on the packed planes after the marching kernel
+        WS_HIP(ctx, launch_prepare(c, m, ia->data, ia->stride, pa, ib->data, ib->stride, pb, pbi,
+                                   p->view == WS_VIEW_LEFT ? &ga : nullptr, s));
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         const int keys_pitch = (c.wa + 15) & ~15;
         if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
@@ -298,12 +305,6 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;
         }
-        if (c.mirror) {
-            ga.skip_x0 = c.wa - c.ox1; ga.skip_x1 = c.wa - c.ox0;
-        } else {
-            ga.skip_x0 = c.ox0; ga.skip_x1 = c.ox1;
-        }
-        ga.skip_y0 = c.oy0; ga.skip_y1 = c.oy1;
         ctx->last_kernel = march_kernel_name(c, m);
         ctx->last_threads = m.threads;
         ctx->last_wgs = m.tiles * m.strips;
@@ -317,7 +318,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     // everything the marching kernel does not own: border ring, rows past min(h1,h2), or all of it
     if (march && p->view == WS_VIEW_RIGHT)
         WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, s));
-    else
+    else if (!march)
         WS_HIP(ctx, launch_generic(ga, s));
     ctx->last_march = march;
     if (march) {

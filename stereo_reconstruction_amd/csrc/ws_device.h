@@ -111,6 +111,74 @@ __device__ __forceinline__ bool ring_pixel(const GenericArgs &g, int ow, int oh,
     return true;
 }
 
+// One output pixel of the literal brute force on the original images; idx enumerates the pixels
+// outside the skip rectangle (ring_pixel).
+__device__ __forceinline__ void generic_pixel(const GenericArgs &g, long long idx)
+{
+    const int ow = g.view == 0 ? g.w1 : g.w2, oh = g.view == 0 ? g.h1 : g.h2;
+    int x, y;
+    if (!ring_pixel(g, ow, oh, idx, &x, &y)) return;
+    const int height = min(g.h1, g.h2);
+    float val = 0.0f;
+    if (g.view == 0) { // BlockSearch.cpp:24-86
+        const int half = (g.block_size - 1) / 2;
+        if (y >= half && y < height - half && x >= half && x < g.w1 - half &&
+            !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+            const uint8_t *lw = g.L + (size_t)(y - half) * g.s1 + 3 * (x - half);
+            uint32_t best = 0xffffffffu;
+            int best_cx = 0;
+            for (int cx = x - g.max_d; cx < x; ++cx) {
+                if (cx < half || cx >= g.w2 - half) continue;
+                const uint8_t *rw = g.R + (size_t)(y - half) * g.s2 + 3 * (cx - half);
+                const uint32_t cst = window_cost(lw, g.s1, rw, g.s2, g.block_size, g.block_size, g.ssd);
+                if (cst < best) {
+                    best = cst;
+                    best_cx = cx;
+                }
+            }
+            val = (float)(x - best_cx);
+        }
+    } else if (g.view == 1) { // BlockSearch.cpp:88-179 (varBlock off)
+        if (y < height && !black3(g.R + (size_t)y * g.s2 + 3 * x)) {
+            const int half = (g.block_size - 1) / 2;
+            const int left = min(x, half), right = min(g.w2 - x - 1, half);
+            const int up = min(y, half), down = min(g.h2 - y - 1, half);
+            const int ww = left + right, wh = up + down;
+            uint32_t best = 0xffffffffu;
+            int best_cx = 0;
+            if (ww > 0 && wh > 0) { // empty window: 0/0 = NaN never wins (BlockSearch.cpp:158)
+                const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
+                for (int cx = x + g.min_d; cx < x + g.max_d; ++cx) {
+                    if (cx + right >= g.w1) break;
+                    const uint8_t *lw = g.L + (size_t)(y - up) * g.s1 + 3 * (cx - left);
+                    const uint32_t cst = window_cost(lw, g.s1, rw, g.s2, ww, wh, g.ssd);
+                    if (cst < best) {
+                        best = cst;
+                        best_cx = cx;
+                    }
+                }
+            }
+            val = (float)(best_cx - x);
+        }
+    } else { // LinearSearch.cpp:10-59
+        if (y < g.h1 && !(x < g.w1 && black3(g.L + (size_t)y * g.s1 + 3 * x))) {
+            const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
+            uint32_t best = 0xffffffffu;
+            int col = 0;
+            for (int k = x + g.min_d; k < x + g.linear_range; ++k) {
+                if (k >= g.w1) break;
+                const uint32_t cst = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * k, 0, 1, 1, 1);
+                if (cst < best) {
+                    best = cst;
+                    col = k;
+                }
+            }
+            val = (float)(col - x);
+        }
+    }
+    g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
 // wave-wide sum by a butterfly of shuffles
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {

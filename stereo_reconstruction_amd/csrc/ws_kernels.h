@@ -57,10 +57,12 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
 // Plane geometry (pad / pitch) the plan needs.
 void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias);
 
-hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
-                       const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
-                       int centred, hipStream_t s);
-hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s);
+struct GenericArgs;
+// pack both planes, sum the bias rows (SSD) and -- when `generic` is given (left view) -- write the
+// pixels outside the marching interior, all in one launch of independent workgroups
+hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *src_a, int stride_a, Plane dst_a,
+                          const uint8_t *src_b, int stride_b, Plane dst_b, Plane bias, const GenericArgs *generic,
+                          hipStream_t s);
 // keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
                         float *out, int out_pitch, void *keys, int keys_pitch, hipStream_t s);

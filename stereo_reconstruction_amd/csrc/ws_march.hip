@@ -1,5 +1,5 @@
 // ws_march.hip -- the hot kernel of the WindowSearch path on gfx950 (CDNA4), plus the overview of
-// all device code:  ws_prepass.hip (pack, bias), ws_march.hip (marching kernel, tiling plan),
+// all device code:  ws_prepass.hip (pack + bias + border in one launch), ws_march.hip (marching kernel, tiling plan),
 // ws_border.hip (brute force, border ring, refine, varBlock), ws_smooth.hip (smoothFactor passes),
 // ws_consumers.hip (warp, Reconstruction-side maps), ws_device.h (shared helpers).
 //
@@ -8,10 +8,12 @@
 // candidate with the strictly smallest value.  It re-sums the window for every (pixel, d).
 //
 // What runs here instead (same integers, same winner):
-//   ws_pack_kernel   BGR bytes -> one dword per pixel (B | G<<8 | R<<16), zero padded plane,
-//                    mirrored in x for the right view.
-//   ws_bias_kernel   per (row, B column): validity poison, and for SSD the box sum of the
-//                    squared target pixels (the part of sum (a-b)^2 that does not need a).
+//   ws_prepare_kernel  one launch of independent workgroups before the hot kernel:
+//                    pack: BGR bytes -> one dword per pixel (B | G<<8 | R<<16), zero padded plane,
+//                          mirrored in x for the right view;
+//                    bias: per (row, B column) the validity poison, and for SSD the box sum of the
+//                          squared target pixels (the part of sum (a-b)^2 that does not need a);
+//                    left view: the pixels outside the marching interior (border zeros).
 //   ws_march_kernel  the hot kernel.  A workgroup owns a tile of X*nxr columns and a strip of
 //                    rows; thread (r, c) owns X consecutive columns and ND consecutive
 //                    disparities and keeps their X*ND window sums in registers while the

@@ -1,4 +1,5 @@
-// ws_prepass.hip -- pack (BGR bytes -> dword planes) and bias (box-summed squares / poison) kernels
+// ws_prepass.hip -- one launch before the marching kernel: pack (BGR bytes -> dword planes), bias
+// (box-summed squares / poison) and, for the left view, the pixels outside the marching interior
 // Part of the gfx950 kernels of the WindowSearch hot path; overview in ws_march.hip.
 #include "ws_device.h"
 
@@ -15,62 +16,58 @@ struct PackArgs { // blockIdx.z selects the image: both planes are packed by one
     uint32_t xor_mask; // kCentre for SSD planes, 0 for SAD
 };
 
-__global__ void __launch_bounds__(256) ws_pack_kernel(const PackArgs g)
+constexpr int kPackRows = 4; // rows per thread: independent loads in flight, a quarter of the workgroups
+
+__device__ __forceinline__ void pack_block(const PackArgs &g, int z, int bx, int by)
 {
-    // one thread = 4 consecutive plane columns (one 16-byte store); pitch is a multiple of 4
-    const int z = blockIdx.z;
+    // one thread = 4 consecutive plane columns (one 16-byte store) of kPackRows rows; pitch is a multiple of 4
     const int w = g.w[z], h = g.h[z], pitch = g.pitch[z];
-    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (col >= pitch || y >= h) return;
+    const int col = (bx * 256 + (int)threadIdx.x) * 4;
+    if (col >= pitch) return;
     const int x = col - g.pad[z];
-    const uint8_t *row = g.src[z] + (size_t)y * g.stride[z];
-    uint32_t v[4] = {0u, 0u, 0u, 0u};
-    if (!g.mirror && x >= 0 && x + 3 < w && ((reinterpret_cast<uintptr_t>(row) + 3 * (size_t)x) & 3) == 0) {
-        // 12 bytes = 3 aligned dwords = 4 BGR pixels
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * (size_t)x);
-        const uint32_t a = p[0], b = p[1], c = p[2];
-        v[0] = (a & 0xffffffu) ^ g.xor_mask;
-        v[1] = ((a >> 24) | ((b & 0xffffu) << 8)) ^ g.xor_mask;
-        v[2] = ((b >> 16) | ((c & 0xffu) << 16)) ^ g.xor_mask;
-        v[3] = (c >> 8) ^ g.xor_mask;
-    } else {
+    const int y0 = by * kPackRows;
+    uint32_t v[kPackRows][4];
+    const bool quad = !g.mirror && x >= 0 && x + 3 < w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int xs = x + k;
-            if (xs >= 0 && xs < w) {
-                if (g.mirror) xs = w - 1 - xs;
-                const uint8_t *p = row + (size_t)xs * 3;
-                v[k] = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) ^ g.xor_mask;
+    for (int r = 0; r < kPackRows; ++r) {
+        v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0u;
+        const int y = y0 + r;
+        if (y >= h) continue;
+        const uint8_t *row = g.src[z] + (size_t)y * g.stride[z];
+        if (quad && ((reinterpret_cast<uintptr_t>(row) + 3 * (size_t)x) & 3) == 0) {
+            // 12 bytes = 3 aligned dwords = 4 BGR pixels
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + 3 * (size_t)x);
+            const uint32_t a = p[0], b = p[1], c = p[2];
+            v[r][0] = (a & 0xffffffu) ^ g.xor_mask;
+            v[r][1] = ((a >> 24) | ((b & 0xffffu) << 8)) ^ g.xor_mask;
+            v[r][2] = ((b >> 16) | ((c & 0xffu) << 16)) ^ g.xor_mask;
+            v[r][3] = (c >> 8) ^ g.xor_mask;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int xs = x + k;
+                if (xs >= 0 && xs < w) {
+                    if (g.mirror) xs = w - 1 - xs;
+                    const uint8_t *p = row + (size_t)xs * 3;
+                    v[r][k] = ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) ^ g.xor_mask;
+                }
             }
         }
     }
-    *reinterpret_cast<uint4 *>(g.dst[z] + (size_t)y * pitch + col) = make_uint4(v[0], v[1], v[2], v[3]);
-}
-
-hipError_t launch_pack(const uint8_t *src_a, int wa, int ha, int stride_a, Plane dst_a,
-                       const uint8_t *src_b, int wb, int hb, int stride_b, Plane dst_b, int mirror,
-                       int centred, hipStream_t s)
-{
-    PackArgs g{};
-    g.xor_mask = centred ? kCentre : 0u;
-    g.src[0] = src_a; g.dst[0] = dst_a.data; g.w[0] = wa; g.h[0] = ha; g.stride[0] = stride_a;
-    g.pitch[0] = dst_a.pitch; g.pad[0] = dst_a.pad;
-    g.src[1] = src_b; g.dst[1] = dst_b.data; g.w[1] = wb; g.h[1] = hb; g.stride[1] = stride_b;
-    g.pitch[1] = dst_b.pitch; g.pad[1] = dst_b.pad;
-    g.mirror = mirror;
-    dim3 grid(ceil_div(std::max(dst_a.pitch, dst_b.pitch) / 4, 256), std::max(ha, hb), 2);
-    hipLaunchKernelGGL(ws_pack_kernel, grid, dim3(256), 0, s, g);
-    return hipGetLastError();
+#pragma unroll
+    for (int r = 0; r < kPackRows; ++r)
+        if (y0 + r < h)
+            *reinterpret_cast<uint4 *>(g.dst[z] + (size_t)(y0 + r) * pitch + col) = make_uint4(v[r][0], v[r][1], v[r][2], v[r][3]);
 }
 
 // ------------------------------------------------------------------------------------------
 // bias rows: poison for invalid B centres; for SSD the box-summed squares of B
 // ------------------------------------------------------------------------------------------
 struct BiasArgs {
-    const uint32_t *B;
-    int pitch_b, pad_b; // the packed target plane
-    int pitch, pad;     // the bias plane (own padding: its row copies must start 16-byte aligned)
+    const uint8_t *src; // the target image's bytes (the pack of the same launch may not have run yet)
+    int wb, hb, stride, mirror;
+    uint32_t xor_mask;
+    int pitch, pad; // the bias plane (own padding: its row copies must start 16-byte aligned)
     int ww, wh, wx0, wy0;
     int b_lo, b_hi, oy0, oy1;
     int ssd, shift, centred;
@@ -78,37 +75,81 @@ struct BiasArgs {
 };
 
 constexpr int kBiasRows = 32;  // output rows per workgroup
-constexpr int kBiasMaxWh = 17; // tallest window with a marching instantiation
-
-__device__ __forceinline__ uint32_t row_square_sum(const uint32_t *row, int ww, int centred)
-{
-    uint32_t acc = 0;
-    if (centred)
-        for (int wx = 0; wx < ww; ++wx) acc = pix_dot<true>(row[wx], row[wx], acc);
-    else
-        for (int wx = 0; wx < ww; ++wx) acc = pix_dot<false>(row[wx], row[wx], acc);
-    return acc;
-}
+constexpr int kBiasMaxWh = 17; // tallest (and widest) window with a marching instantiation
 
 // Separable box filter of the squared target pixels: a workgroup (64 x 4 threads) owns 64 columns
-// x kBiasRows rows.  Thread (tx, ty) fills every 4th horizontal sum of column tx in LDS, then
-// slides the vertical sum down its quarter of the strip.
-__global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
+// x kBiasRows rows.  The squares of its pixels (+ window halo) go to LDS straight from the image
+// bytes, then the horizontal sums, then thread (tx, ty) slides the vertical sum down its quarter
+// of the strip.
+__device__ __forceinline__ void bias_block(const BiasArgs &g, int bx, int by, uint32_t (*raw)[64], uint32_t (*sq)[64 + kBiasMaxWh],
+                                           uint32_t (*hs)[64])
 {
-    __shared__ uint32_t hs[kBiasRows + kBiasMaxWh - 1][64];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 64 + tx;
-    const int y0 = g.oy0 + blockIdx.y * kBiasRows;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = bx * 64 + tx;
+    const int y0 = g.oy0 + by * kBiasRows;
     const int y1 = min(y0 + kBiasRows, g.oy1);
     const int xb = col - g.pad;
     const bool in_plane = col < g.pitch;
     const bool centre_ok = in_plane && xb >= g.b_lo && xb <= g.b_hi;
-    if (centre_ok && g.ssd) {
-        const int nrows = (y1 - y0) + g.wh - 1;
-        const uint32_t *src = g.B + (size_t)(y0 + g.wy0) * g.pitch_b + (xb + g.pad_b + g.wx0);
-        for (int k = ty; k < nrows; k += 4) hs[k][tx] = row_square_sum(src + (size_t)k * g.pitch_b, g.ww, g.centred);
+    if (g.ssd) {
+        const int nrows = (y1 - y0) + g.wh - 1, ncols = 64 + g.ww - 1;
+        const int xc0 = bx * 64 - g.pad + g.wx0; // canonical column of sq[.][0]
+        // the image columns behind sq[.][0 .. ncols): one contiguous byte range per row
+        const int ca = max(xc0, 0), cb = min(xc0 + ncols, g.wb); // canonical [ca, cb)
+        const int xs_lo = g.mirror ? g.wb - cb : ca;             // first image column of the range
+        constexpr int kMaxTrips = (kBiasRows + kBiasMaxWh - 1 + 3) / 4;
+        // (1) the rows' bytes as aligned dwords, every load of a thread in flight at once
+        uint32_t ld[kMaxTrips];
+#pragma unroll
+        for (int t = 0; t < kMaxTrips; ++t) {
+            const int k = ty + 4 * t, yy = y0 + g.wy0 + k;
+            ld[t] = 0;
+            if (k < nrows && yy >= 0 && yy < g.hb && cb > ca) {
+                const uintptr_t first = reinterpret_cast<uintptr_t>(g.src + (size_t)yy * g.stride + 3 * (size_t)xs_lo);
+                const uintptr_t a0 = first & ~(uintptr_t)3;
+                const int ndw = (int)((first + 3 * (size_t)(cb - ca) + 3 - a0) >> 2); // an aligned dword holding an image
+                if (tx < ndw) ld[t] = reinterpret_cast<const uint32_t *>(a0)[tx];    // byte stays inside its page
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kMaxTrips; ++t) {
+            const int k = ty + 4 * t;
+            if (k < nrows) raw[k][tx] = ld[t];
+        }
+        __syncthreads();
+        // (2) squares of the pixels
+#pragma unroll 4
+        for (int k = ty; k < nrows; k += 4) {
+            const int yy = y0 + g.wy0 + k;
+            const bool row_ok = yy >= 0 && yy < g.hb;
+            const uint32_t sh0 = row_ok ? (uint32_t)(reinterpret_cast<uintptr_t>(g.src + (size_t)yy * g.stride + 3 * (size_t)xs_lo) & 3) : 0u;
+            for (int cx = tx; cx < ncols; cx += 64) {
+                const int xc = xc0 + cx;
+                uint32_t v = 0;
+                if (row_ok && xc >= ca && xc < cb) {
+                    const uint32_t off = sh0 + 3u * (uint32_t)(g.mirror ? cb - 1 - xc : xc - ca); // byte offset in raw[k]
+                    const uint32_t lo = raw[k][off >> 2], hi = raw[k][(off >> 2) + 1];
+                    const uint32_t px = (__builtin_amdgcn_alignbyte(hi, lo, off & 3u) & 0xffffffu) ^ g.xor_mask;
+                    v = g.centred ? pix_dot<true>(px, px, 0u) : pix_dot<false>(px, px, 0u);
+                }
+                sq[k][cx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = ty; k < nrows; k += 4) {
+            uint32_t acc = 0;
+            if (g.ww == 7) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) acc += sq[k][tx + i];
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < g.ww; ++i) acc += sq[k][tx + i];
+            }
+            hs[k][tx] = acc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (!in_plane) return;
     const int seg = kBiasRows / 4;
     const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
@@ -120,7 +161,9 @@ __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
         return;
     }
     uint32_t acc = 0;
+#pragma unroll 8
     for (int k = 0; k < g.wh; ++k) acc += hs[ya - y0 + k][tx];
+#pragma unroll 8
     for (int y = ya; y < yb; ++y, dst += g.pitch) {
         *dst = (int32_t)(acc << g.shift);
         const int k = y - y0;
@@ -128,28 +171,75 @@ __global__ void __launch_bounds__(256) ws_bias_kernel(const BiasArgs g)
     }
 }
 
-hipError_t launch_bias(const Canon &c, const MarchLaunch &m, Plane b, Plane bias, hipStream_t s)
+// ------------------------------------------------------------------------------------------
+// One launch for everything the marching kernel needs and everything beside it that only reads
+// the images: the first nBias workgroups sum the bias rows, the next nA pack the reference plane, then
+// nB the target plane, the rest (left view) write the pixels outside the marching interior.
+// The four jobs are independent, so the small ones fill the CUs together instead of one after
+// the other.
+// ------------------------------------------------------------------------------------------
+struct PrepareArgs {
+    PackArgs pack;
+    BiasArgs bias;
+    GenericArgs generic;
+    int pack_gx[2], n_pack[2];
+    int bias_gx, n_bias;
+    int n_generic;
+};
+
+__global__ void __launch_bounds__(256) ws_prepare_kernel(const PrepareArgs g)
 {
-    BiasArgs g{};
-    g.B = b.data;
-    g.pitch_b = b.pitch;
-    g.pad_b = b.pad;
-    g.pitch = bias.pitch;
-    g.pad = bias.pad;
-    g.ww = c.ww;
-    g.wh = c.wh;
-    g.wx0 = c.wx0;
-    g.wy0 = c.wy0;
-    g.b_lo = c.b_lo;
-    g.b_hi = c.b_hi;
-    g.oy0 = c.oy0;
-    g.oy1 = c.oy1;
-    g.ssd = c.ssd;
-    g.shift = ilog2c(m.nd_per_thread);
-    g.centred = march_centred(c);
-    g.bias = reinterpret_cast<int32_t *>(bias.data);
-    dim3 grid(ceil_div(bias.pitch, 64), ceil_div(c.oy1 - c.oy0, kBiasRows));
-    hipLaunchKernelGGL(ws_bias_kernel, grid, dim3(64, 4), 0, s, g);
+    // static LDS bounds the occupancy of every role: the raw bytes ((64 + 16) * 3 + alignment slack
+    // < 256 per row) are dead once the squares exist, the horizontal sums reuse their space
+    __shared__ uint32_t raw[kBiasRows + kBiasMaxWh - 1][64];
+    __shared__ uint32_t sq[kBiasRows + kBiasMaxWh - 1][64 + kBiasMaxWh];
+    uint32_t (*hs)[64] = raw;
+    int b = blockIdx.x; // the longest-running workgroups first
+    if (b < g.n_bias) { bias_block(g.bias, b % g.bias_gx, b / g.bias_gx, raw, sq, hs); return; }
+    b -= g.n_bias;
+    if (b < g.n_pack[0]) { pack_block(g.pack, 0, b % g.pack_gx[0], b / g.pack_gx[0]); return; }
+    b -= g.n_pack[0];
+    if (b < g.n_pack[1]) { pack_block(g.pack, 1, b % g.pack_gx[1], b / g.pack_gx[1]); return; }
+    b -= g.n_pack[1];
+    generic_pixel(g.generic, (long long)b * 256 + threadIdx.x);
+}
+
+hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *src_a, int stride_a, Plane dst_a,
+                          const uint8_t *src_b, int stride_b, Plane dst_b, Plane bias, const GenericArgs *generic,
+                          hipStream_t s)
+{
+    PrepareArgs g{};
+    const int centred = march_centred(c);
+    g.pack.xor_mask = centred ? kCentre : 0u;
+    g.pack.src[0] = src_a; g.pack.dst[0] = dst_a.data; g.pack.w[0] = c.wa; g.pack.h[0] = c.ha; g.pack.stride[0] = stride_a;
+    g.pack.pitch[0] = dst_a.pitch; g.pack.pad[0] = dst_a.pad;
+    g.pack.src[1] = src_b; g.pack.dst[1] = dst_b.data; g.pack.w[1] = c.wb; g.pack.h[1] = c.hb; g.pack.stride[1] = stride_b;
+    g.pack.pitch[1] = dst_b.pitch; g.pack.pad[1] = dst_b.pad;
+    g.pack.mirror = c.mirror;
+    g.pack_gx[0] = ceil_div(dst_a.pitch / 4, 256); g.n_pack[0] = g.pack_gx[0] * ceil_div(c.ha, kPackRows);
+    g.pack_gx[1] = ceil_div(dst_b.pitch / 4, 256); g.n_pack[1] = g.pack_gx[1] * ceil_div(c.hb, kPackRows);
+    if (c.ssd) {
+        BiasArgs &bi = g.bias;
+        bi.src = src_b; bi.wb = c.wb; bi.hb = c.hb; bi.stride = stride_b; bi.mirror = c.mirror;
+        bi.xor_mask = g.pack.xor_mask;
+        bi.pitch = bias.pitch; bi.pad = bias.pad;
+        bi.ww = c.ww; bi.wh = c.wh; bi.wx0 = c.wx0; bi.wy0 = c.wy0;
+        bi.b_lo = c.b_lo; bi.b_hi = c.b_hi; bi.oy0 = c.oy0; bi.oy1 = c.oy1;
+        bi.ssd = c.ssd; bi.shift = ilog2c(m.nd_per_thread); bi.centred = centred;
+        bi.bias = reinterpret_cast<int32_t *>(bias.data);
+        if (c.ww > kBiasMaxWh || c.wh > kBiasMaxWh) return hipErrorInvalidValue;
+        g.bias_gx = ceil_div(bias.pitch, 64);
+        g.n_bias = g.bias_gx * ceil_div(c.oy1 - c.oy0, kBiasRows);
+    }
+    if (generic) {
+        g.generic = *generic;
+        const int ow = generic->view == 0 ? generic->w1 : generic->w2, oh = generic->view == 0 ? generic->h1 : generic->h2;
+        const long long inside = (long long)(generic->skip_x1 - generic->skip_x0) * (generic->skip_y1 - generic->skip_y0);
+        const long long n = (long long)ow * oh - (inside > 0 ? inside : 0);
+        g.n_generic = n > 0 ? (int)((n + 255) / 256) : 0;
+    }
+    const long long total = (long long)g.n_pack[0] + g.n_pack[1] + g.n_bias + g.n_generic;
+    hipLaunchKernelGGL(ws_prepare_kernel, dim3((unsigned)total), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
