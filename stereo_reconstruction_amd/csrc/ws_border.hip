@@ -14,14 +14,12 @@ __global__ void __launch_bounds__(256) ws_generic_kernel(const GenericArgs g)
 }
 
 // ------------------------------------------------------------------------------------------
-// right-view border ring: clipped windows (BlockSearch.cpp:116-123), one wave per pixel
+// right-view border ring: clipped windows (BlockSearch.cpp:116-123), sliding sums along runs
 //
 // The marching kernel owns the pixels whose (bs-1)^2 window is complete.  On the ring the window
 // is clipped by the image border, so its size changes from pixel to pixel; there are only
-// ~2*half*(W+H) such pixels.  One wavefront takes one pixel: the 64 lanes take 64 consecutive
-// disparities at a time (consecutive lanes read consecutive target pixels), every lane sums its
-// own window on the packed planes, keeps its best candidate, and a wave-wide min over
-// (cost, d) keys -- butterfly of shuffles -- picks the winner with the reference's tie rule.
+// ~2*half*(W+H) such pixels.  They are taken in short runs along the border (rows of the top /
+// bottom band, columns of the side bands), lanes over d, see ws_ring_kernel below.
 // ------------------------------------------------------------------------------------------
 struct RingArgs {
     const uint32_t *A;
@@ -36,64 +34,132 @@ struct RingArgs {
     int out_pitch;
 };
 
-__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g)
+constexpr int kRingRun = 32; // most ring pixels per workgroup: one window sum, then up to kRingRun - 1 slides
+
+// cost of one window line (n pixels, strides sa / sb: a row or a column of the window)
+template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
+__device__ __forceinline__ int32_t ring_line(const uint32_t *pa, const uint32_t *pb, int n, size_t sa, size_t sb)
 {
-    const int lane = threadIdx.x & 63;
-    // the pixel is the same for the whole wave: keep it (and every address derived from it) in
-    // scalar registers, so the window of plane A is fetched by scalar loads
-    const long long pix = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    GenericArgs e{}; // only the skip rectangle is used by ring_pixel
-    e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
-    int x, y;
-    if (!ring_pixel(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
-    const int xm = g.wa - 1 - x; // canonical (mirrored) column
-    float val = 0.0f;
-    const uint32_t black = g.centred ? kCentre : 0u;
-    if (y < g.height && g.A[(size_t)y * g.pitch_a + xm + g.pad_a] != black) {
-        const int left = min(x, g.half), right = min(g.wa - x - 1, g.half);
-        const int up = min(y, g.half), down = min(g.ha - y - 1, g.half);
-        const int ww = left + right, wh = up + down;
-        // candidates: d_lo <= d <= d_hi with x + d + right < w1 (BlockSearch.cpp:147-149)
-        const int d_end = min(g.d_hi, g.wb - right - x - 1);
-        long long best = LLONG_MAX;
-        if (ww > 0 && wh > 0) {
-            const int c0 = xm - right + 1; // first window column, canonical
-            const uint32_t *arow0 = g.A + (size_t)(y - up) * g.pitch_a + c0 + g.pad_a;
-            for (int d = g.d_lo + lane; d <= d_end; d += 64) {
-                const uint32_t *brow0 = g.B + (size_t)(y - up) * g.pitch_b + (c0 - d + g.boff + g.pad_b);
-                int32_t cost = 0;
-                for (int r = 0; r < wh; ++r) {
-                    const uint32_t *pa = arow0 + (size_t)r * g.pitch_a;
-                    const uint32_t *pb = brow0 + (size_t)r * g.pitch_b;
-                    if (!g.ssd) {
-                        uint32_t acc = 0;
-                        for (int i = 0; i < ww; ++i) acc = pix_sad(pa[i], pb[i], acc);
-                        cost += (int32_t)acc;
-                    } else if (g.centred) {
-                        uint32_t bb = 0, ab = 0; // sum (a-b)^2 = sum a^2 + [sum b^2 - 2 sum ab]; sum a^2 is the same for every d
-                        for (int i = 0; i < ww; ++i) {
-                            bb = pix_dot<true>(pb[i], pb[i], bb);
-                            ab = pix_dot<true>(pa[i], pb[i], ab);
-                        }
-                        cost += (int32_t)bb - 2 * (int32_t)ab;
-                    } else {
-                        uint32_t bb = 0, ab = 0;
-                        for (int i = 0; i < ww; ++i) {
-                            bb = pix_dot<false>(pb[i], pb[i], bb);
-                            ab = pix_dot<false>(pa[i], pb[i], ab);
-                        }
-                        cost += (int32_t)bb - 2 * (int32_t)ab;
-                    }
-                }
-                const long long key = ((long long)cost << 32) | (uint32_t)d; // ties: smaller d
-                best = min(best, key);
-            }
+    if constexpr (MODE == 0) {
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) acc = pix_sad(pa[i * sa], pb[i * sb], acc);
+        return (int32_t)acc;
+    } else {
+        // sum (a-b)^2 = sum a^2 + [sum b^2 - 2 sum ab]; sum a^2 is the same for every d
+        uint32_t bb = 0, ab = 0;
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {
+            const uint32_t va = pa[i * sa], vb = pb[i * sb];
+            bb = pix_dot<MODE == 2>(vb, vb, bb);
+            ab = pix_dot<MODE == 2>(va, vb, ab);
         }
-        // wave-wide min: butterfly over the 64 lanes
-        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
-        val = best == LLONG_MAX ? -(float)x : (float)(uint32_t)(best & 0xffffffffll);
+        return (int32_t)bb - 2 * (int32_t)ab;
     }
-    if (lane == 0) g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
+// The clipped window of ring pixel (x, y), original coordinates -> canonical columns [ca, ce), rows [ra, re)
+struct RingWin { int ca, ce, ra, re, d_end; };
+__device__ __forceinline__ RingWin ring_window(const RingArgs &g, int x, int y)
+{
+    const int left = min(x, g.half), right = min(g.wa - x - 1, g.half);
+    const int up = min(y, g.half), down = min(g.ha - y - 1, g.half);
+    const int xm = g.wa - 1 - x;
+    RingWin w;
+    w.ca = xm - right + 1; w.ce = w.ca + left + right;
+    w.ra = y - up; w.re = y + down;
+    w.d_end = min(g.d_hi, g.wb - right - x - 1); // x + d + right < w1 (BlockSearch.cpp:147-149)
+    return w;
+}
+
+// One workgroup = a run of kRingRun ring pixels along a row (top / bottom band) or along a column
+// (side bands); its four waves take every fourth group of 64 consecutive disparities (lane = d).
+// The first pixel's window is summed in full, every next one is the previous one minus the line
+// that left plus the line that entered (the clipped windows of neighbouring ring pixels differ by
+// at most one line at either end).  The costs of a group go to LDS ([d][pixel], padded), then lane
+// (pixel, half) scans 32 disparities in ascending order -- the reference's tie rule -- and the
+// groups meet in one 64-bit LDS min per pixel.
+template <int MODE>
+__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int n_hruns, int hruns_per_row, int vruns_per_col, int rl)
+{
+    __shared__ int32_t costs[4][64][kRingRun + 1];
+    __shared__ long long best[kRingRun];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the run is the same for the whole workgroup: every address derived from it stays in scalar
+    // registers, so the window of plane A is fetched by scalar loads
+    const int run = blockIdx.x;
+    const bool horizontal = run < n_hruns;
+    int x0, y0, n;
+    if (horizontal) {
+        const int rowi = run / hruns_per_row;
+        y0 = rowi < g.skip_y0 ? rowi : g.skip_y1 + (rowi - g.skip_y0);
+        x0 = (run % hruns_per_row) * rl;
+        n = min(rl, g.wa - x0);
+    } else {
+        const int v = run - n_hruns, coli = v / vruns_per_col;
+        x0 = coli < g.skip_x0 ? coli : g.skip_x1 + (coli - g.skip_x0);
+        y0 = g.skip_y0 + (v % vruns_per_col) * rl;
+        n = min(rl, g.skip_y1 - y0);
+    }
+    if (threadIdx.x < kRingRun) best[threadIdx.x] = LLONG_MAX;
+    __syncthreads();
+    const size_t pa_ = g.pitch_a, pb_ = g.pitch_b;
+    for (int dbase = g.d_lo + 64 * wave; dbase <= g.d_hi; dbase += 256) {
+        const int d = dbase + lane;
+        int32_t cost = 0;
+        RingWin w{};
+        bool have = false; // cost holds the window w for the lanes whose d is a candidate there
+        const uint32_t *A0 = g.A + g.pad_a, *B0 = g.B + (g.boff + g.pad_b - d);
+        for (int i = 0; i < n; ++i) {
+            const int x = horizontal ? x0 + i : x0, y = horizontal ? y0 : y0 + i;
+            const RingWin nw = ring_window(g, x, y);
+            const bool empty = nw.ce <= nw.ca || nw.re <= nw.ra; // 0/0 = NaN never wins (BlockSearch.cpp:158)
+            const bool valid = !empty && d <= nw.d_end; // candidates only drop out along a run, never join
+            if (valid) {
+                if (!have) {
+                    cost = 0;
+                    for (int r = nw.ra; r < nw.re; ++r)
+                        cost += ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
+                } else if (horizontal) { // x + 1: the canonical window moves towards lower columns
+                    for (int c = nw.ce; c < w.ce; ++c)
+                        cost -= ring_line<MODE>(A0 + nw.ra * pa_ + c, B0 + nw.ra * pb_ + c, nw.re - nw.ra, pa_, pb_);
+                    for (int c = nw.ca; c < w.ca; ++c)
+                        cost += ring_line<MODE>(A0 + nw.ra * pa_ + c, B0 + nw.ra * pb_ + c, nw.re - nw.ra, pa_, pb_);
+                } else { // y + 1
+                    for (int r = w.ra; r < nw.ra; ++r)
+                        cost -= ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
+                    for (int r = w.re; r < nw.re; ++r)
+                        cost += ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
+                }
+            }
+            have = !empty;
+            w = nw;
+            costs[wave][lane][i] = valid ? cost : INT_MAX; // (a real cost stays far below INT_MAX)
+        }
+        // this wave's 64 disparities of pixel p: two lanes scan 32 each, ascending d, strict '<'
+        const int p = lane & 31, part = lane >> 5;
+        int32_t bc = INT_MAX;
+        int bd = 0;
+        if (p < n) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int32_t c = costs[wave][part * 32 + k][p];
+                if (c < bc) { bc = c; bd = dbase + part * 32 + k; }
+            }
+            if (bc != INT_MAX) atomicMin(&best[p], ((long long)bc << 32) | (uint32_t)bd); // ties: smaller d
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n) {
+        const int i = threadIdx.x;
+        const int x = horizontal ? x0 + i : x0, y = horizontal ? y0 : y0 + i;
+        const uint32_t black = MODE == 2 ? kCentre : 0u;
+        float val = 0.0f;
+        if (y < g.height && g.A[(size_t)y * g.pitch_a + (g.wa - 1 - x) + g.pad_a] != black)
+            val = best[i] == LLONG_MAX ? -(float)x : (float)(uint32_t)(best[i] & 0xffffffffll);
+        g.out[(size_t)y * g.out_pitch + x] = val;
+    }
 }
 
 hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
@@ -108,11 +174,24 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
     g.boff = c.boff; g.d_lo = c.d_lo; g.d_hi = c.d_hi;
     g.ssd = c.ssd; g.centred = march_centred(c);
     g.skip_x0 = skip.skip_x0; g.skip_x1 = skip.skip_x1; g.skip_y0 = skip.skip_y0; g.skip_y1 = skip.skip_y1;
+    if (g.skip_x1 <= g.skip_x0 || g.skip_y1 <= g.skip_y0) { // no interior: every row is a "top" row
+        g.skip_x0 = g.skip_x1 = 0;
+        g.skip_y0 = g.skip_y1 = c.ha;
+    }
     g.out = out; g.out_pitch = out_pitch;
-    const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
-    const long long n = (long long)c.wa * c.ha - (inside > 0 ? inside : 0);
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ws_ring_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g);
+    // run length: long runs amortise the first full window, short ones give more workgroups
+    int rl = 8; // (measured 4 .. 32 at 7x7, 11x11, 17x17: flat between 4 and 16)
+    if (const char *e = getenv("WS_RING_RUN")) rl = std::max(1, std::min(kRingRun, atoi(e))); // development knob
+    const int hruns_per_row = ceil_div(c.wa, rl);
+    const int n_hruns = (g.skip_y0 + (c.ha - g.skip_y1)) * hruns_per_row;
+    const int vruns_per_col = ceil_div(g.skip_y1 - g.skip_y0, rl);
+    const int n_vruns = (g.skip_x0 + (c.wa - g.skip_x1)) * vruns_per_col;
+    if (n_hruns + n_vruns <= 0) return hipSuccess;
+    dim3 grid((unsigned)(n_hruns + n_vruns));
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, g, n_hruns, hruns_per_row, vruns_per_col, rl); };
+    if (!g.ssd) launch(ws_ring_kernel<0>);
+    else if (!g.centred) launch(ws_ring_kernel<1>);
+    else launch(ws_ring_kernel<2>);
     return hipGetLastError();
 }
 
