@@ -32,6 +32,8 @@ struct RingArgs {
     int skip_x0, skip_x1, skip_y0, skip_y1; // marching interior, ORIGINAL coordinates
     float *out;
     int out_pitch;
+    int32_t *cost_out; // optional: the winner's cost (SSD: without the sum of a^2), for the smoothFactor passes
+    int cost_pitch;
 };
 
 constexpr int kRingRun = 32; // most ring pixels per workgroup: one window sum, then up to kRingRun - 1 slides
@@ -159,11 +161,12 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int n_hr
         if (y < g.height && g.A[(size_t)y * g.pitch_a + (g.wa - 1 - x) + g.pad_a] != black)
             val = best[i] == LLONG_MAX ? -(float)x : (float)(uint32_t)(best[i] & 0xffffffffll);
         g.out[(size_t)y * g.out_pitch + x] = val;
+        if (g.cost_out && best[i] != LLONG_MAX) g.cost_out[(size_t)y * g.cost_pitch + x] = (int32_t)(best[i] >> 32);
     }
 }
 
 hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
-                       hipStream_t s)
+                       int32_t *cost_out, int cost_pitch, hipStream_t s)
 {
     RingArgs g{};
     g.A = a.data; g.B = b.data;
@@ -179,6 +182,7 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
         g.skip_y0 = g.skip_y1 = c.ha;
     }
     g.out = out; g.out_pitch = out_pitch;
+    g.cost_out = cost_out; g.cost_pitch = cost_pitch;
     // run length: long runs amortise the first full window, short ones give more workgroups
     int rl = 8; // (measured 4 .. 32 at 7x7, 11x11, 17x17: flat between 4 and 16)
     if (const char *e = getenv("WS_RING_RUN")) rl = std::max(1, std::min(kRingRun, atoi(e))); // development knob

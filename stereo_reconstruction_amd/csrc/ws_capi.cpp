@@ -46,7 +46,7 @@ struct ws_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, keys, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, bias, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
     std::vector<Job> jobs;
     std::string err;
     std::string last_kernel;
@@ -57,6 +57,8 @@ struct ws_context {
     Canon last_canon{};
     Plane last_pa{}, last_pb{};
     int last_skip[4] = {0, 0, 0, 0};
+    bool want_cost = false;       // run_search: also leave the winners' costs (right view, smoothFactor)
+    int32_t *last_cost = nullptr; // where it left them (pitch = plane width), or null
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
 };
 
@@ -208,7 +210,9 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     if (!smooth) return run_search(ctx, &q, L, R, out, out_stride, s);
     q.min_disparity = 1; // the data-parallel part: best candidate among d >= 1
     q.subpixel = 0;
+    ctx->want_cost = p->view == WS_VIEW_RIGHT && !p->var_block;
     int rc = run_search(ctx, &q, L, R, out, out_stride, s);
+    ctx->want_cost = false;
     if (rc != WS_OK) return rc;
     const int sel_pitch = (R->width + 63) & ~63;
     if ((rc = ensure(ctx, ctx->sel, (size_t)sel_pitch * (smooth_sel_rows(R->height) + 64))) != WS_OK) return rc;
@@ -225,14 +229,15 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ga.bs_pitch = (R->width + 63) & ~63;
     }
     if ((rc = ensure(ctx, ctx->sel_planes, smooth_planes_bytes(R->width, R->height))) != WS_OK) return rc;
-    const bool on_planes = p->view == WS_VIEW_RIGHT && !p->var_block && ctx->last_march;
+    const bool on_planes = p->view == WS_VIEW_RIGHT && !p->var_block && ctx->last_march && ctx->last_cost;
     if (on_planes) {
         ga.skip_x0 = ctx->last_skip[0]; ga.skip_x1 = ctx->last_skip[1];
         ga.skip_y0 = ctx->last_skip[2]; ga.skip_y1 = ctx->last_skip[3];
     }
     WS_HIP(ctx, launch_smooth(ga, p->smooth_factor, static_cast<uint8_t *>(ctx->sel.p), sel_pitch,
                               static_cast<unsigned long long *>(ctx->sel_planes.p),
-                              on_planes ? &ctx->last_canon : nullptr, ctx->last_pa, ctx->last_pb, s));
+                              on_planes ? &ctx->last_canon : nullptr, ctx->last_pa, ctx->last_pb,
+                              on_planes ? ctx->last_cost : nullptr, on_planes ? ctx->last_canon.wa : 0, s));
     if (p->subpixel) return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with smoothFactor != 1");
     return WS_OK;
 }
@@ -252,6 +257,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
 
+    ctx->last_cost = nullptr;
     if (p->view == WS_VIEW_RIGHT) ctx->var_block_ran = false;
     if (p->view == WS_VIEW_RIGHT && p->var_block) {
         // per-pixel windows: no sliding sums, one wave per pixel (ws_varblock_kernel)
@@ -300,7 +306,13 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         const int keys_pitch = (c.wa + 15) & ~15;
         if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
-        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, ctx->keys.p, keys_pitch, s));
+        int32_t *cost_out = nullptr; // the smoothFactor passes of the right view want the winners' costs
+        if (ctx->want_cost) {
+            if ((rc = ensure(ctx, ctx->cost, (size_t)c.wa * c.ha * 4)) != WS_OK) return rc;
+            cost_out = static_cast<int32_t *>(ctx->cost.p);
+        }
+        ctx->last_cost = cost_out;
+        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;
@@ -317,7 +329,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     }
     // everything the marching kernel does not own: border ring, rows past min(h1,h2), or all of it
     if (march && p->view == WS_VIEW_RIGHT)
-        WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, s));
+        WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, ctx->last_cost, c.wa, s));
     else if (!march)
         WS_HIP(ctx, launch_generic(ga, s));
     ctx->last_march = march;
@@ -401,7 +413,7 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.pin_in) (void)hipHostFree(j.pin_in);

@@ -65,7 +65,8 @@ hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *s
                           hipStream_t s);
 // keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, void *keys, int keys_pitch, hipStream_t s);
+                        float *out, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
+                        hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2)
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 
 // Brute-force kernels on the original 8-bit images (original coordinates, literal rules).
@@ -83,9 +84,9 @@ struct GenericArgs {
     int bs_pitch;
 };
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
-// Right-view border ring on the packed (mirrored) planes: one wave per pixel, lanes over d.
+// Right-view border ring on the packed (mirrored) planes: sliding sums along runs, lanes over d.
 hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
-                       hipStream_t s);
+                       int32_t *cost_out, int cost_pitch, hipStream_t s);
 // Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // the same for the marching interior, on the packed planes (launch_refine then skips g's skip rectangle)
@@ -101,9 +102,10 @@ size_t smooth_left_top_bytes(int w, int h);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);
 // canon / pa / pb: the right view's canonical search and packed planes when the marching kernel ran
-// (g's skip rectangle = its interior), else canon == nullptr
+// (g's skip rectangle = its interior) together with the cost plane it and the ring kernel wrote,
+// else canon == nullptr
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
-                         const Canon *canon, Plane pa, Plane pb, hipStream_t st);
+                         const Canon *canon, Plane pa, Plane pb, const int32_t *cost, int cost_pitch, hipStream_t st);
 // nearest-neighbour perspective warp of a float map; minv maps destination -> source pixels
 hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int dw, int dh, int dp,
                        const double minv[9], hipStream_t s);

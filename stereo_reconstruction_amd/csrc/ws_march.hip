@@ -57,6 +57,8 @@ struct MarchArgs {
     int strip_rows, tiles, strips;
     int prefer_large, mirror, fallback_neg;
     int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
+    int32_t *cost_out; // optional (smoothFactor passes): the winner's cost, SSD without the sum of a^2
+    int cost_pitch;
 };
 
 // LDS row layout.  A thread reads runs of consecutive pixels starting at column X*r; with a
@@ -287,6 +289,12 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
                     if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
                     g.out[(size_t)y * g.out_pitch + xo] = val;
+                    if (g.cost_out && key != kEmpty) {
+                        int32_t cst;
+                        if constexpr (SSD) cst = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+                        else cst = (int32_t)key >> g.tag_bits;
+                        g.cost_out[(size_t)y * g.cost_pitch + xo] = cst;
+                    }
                 }
             }
         }
@@ -502,7 +510,8 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &)
 }
 
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, void *keys, int keys_pitch, hipStream_t s)
+                        float *out, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
+                        hipStream_t s)
 {
     const MarchEntry *e = find_march(c);
     if (!e) return hipErrorInvalidValue;
@@ -548,6 +557,8 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     dim3 grid(round_up(m.tiles * m.strips, 8));
     g.keys = keys;
     g.keys_pitch = keys_pitch;
+    g.cost_out = cost_out;
+    g.cost_pitch = cost_pitch;
     for (int pass = 0; pass < m.passes; ++pass) {
         g.d_first = c.d_lo + pass * m.nch * m.nd_per_thread;
         g.pass_mode = m.passes == 1 ? 0 : pass == 0 ? 1 : pass == m.passes - 1 ? 3 : 2;

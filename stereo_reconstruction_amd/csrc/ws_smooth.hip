@@ -26,8 +26,6 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= g.w2 || y >= g.h2) return;
-    // (the marching interior, if any, is prepared on the packed planes: ws_smooth_prepare_planes_kernel)
-    if (x >= g.skip_x0 && x < g.skip_x1 && y >= g.skip_y0 && y < g.skip_y1) return;
     float *o = g.out + (size_t)y * g.out_pitch + x;
     uint8_t code = kSelFixed;
     float val = 0.0f;
@@ -89,82 +87,176 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
     sel[(size_t)y * sel_pitch + x] = code;
 }
 
-// The same for the right view's marching interior (complete windows) on the packed, mirrored planes:
-// five v_dot4 (or two v_sad_u8) per window pixel for both costs instead of byte arithmetic.
+// The same for the right view when the marching kernel ran, on the packed, mirrored planes.  The
+// winner's cost c1 comes from the search itself (cost plane; for SSD without the sum of a^2), so
+// what is left per pixel is the cost of d = 0 and, for SSD, the sum of a^2 over the window: two
+// box sums.  Interior (complete windows): separable box filter through LDS, a workgroup per
+// 64 x 32 tile.  Border ring (clipped windows): one thread per ring pixel.
 struct PreparePlanesArgs {
     const uint32_t *A;
     const uint32_t *B;
     int pitch_a, pad_a, pitch_b, pad_b;
-    int wa, ww, wh, wx0, wy0, boff;
+    int wa, ha, wb, height, half, max_d; // ring: plane sizes, min(h1,h2), (bs-1)/2, maxDisparity
+    int ww, wh, wx0, wy0, boff;
     int d_hi, b_lo;
-    int ox0, ox1, oy0, oy1;
+    int ox0, ox1, oy0, oy1;                 // marching interior, canonical
+    int skip_x0, skip_x1, skip_y0, skip_y1; // the same, ORIGINAL coordinates
     double s;
     float *out;
     int out_pitch;
+    const int32_t *cost;
+    int cost_pitch;
     uint8_t *sel;
     int sel_pitch;
 };
 
-template <bool SSD, bool CENTRED>
-__global__ void __launch_bounds__(256) ws_smooth_prepare_planes_kernel(const PreparePlanesArgs g)
+// the three outcomes t_k = [c1 < c0 * s^k] with the reference's doubles
+template <bool SSD>
+__device__ __forceinline__ uint8_t smooth_code(long long c0, long long c1, double area, double s)
 {
-    const int x = g.ox0 + blockIdx.x * blockDim.x + threadIdx.x; // canonical (mirrored) column
-    const int y = g.oy0 + blockIdx.y;
-    if (x >= g.ox1 || y >= g.oy1) return;
+    const double e1 = (SSD ? sqrt((double)c1) : (double)c1) / area;
+    double e0 = (SSD ? sqrt((double)c0) : (double)c0) / area;
+    uint8_t code = 0;
+    if (e1 < e0) code |= 1;
+    e0 *= s;
+    if (e1 < e0) code |= 2;
+    e0 *= s;
+    if (e1 < e0) code |= 4;
+    return code;
+}
+
+constexpr int kBoxRows = 32, kBoxMaxW = 16; // tile rows; widest / tallest right-view marching window
+
+template <bool SSD, bool CENTRED>
+__global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const PreparePlanesArgs g)
+{
+    __shared__ uint32_t e0[kBoxRows + kBoxMaxW - 1][64 + kBoxMaxW];
+    __shared__ uint32_t ea[SSD ? kBoxRows + kBoxMaxW - 1 : 1][64 + kBoxMaxW];
+    __shared__ uint32_t h0[kBoxRows + kBoxMaxW - 1][64];
+    __shared__ uint32_t ha[SSD ? kBoxRows + kBoxMaxW - 1 : 1][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int xt = g.ox0 + blockIdx.x * 64, y0 = g.oy0 + blockIdx.y * kBoxRows;
+    const int y1 = min(y0 + kBoxRows, g.oy1);
+    const int nrows = (y1 - y0) + g.wh - 1, ncols = 64 + g.ww - 1;
+    // (1) per pixel: cost against the d = 0 partner, and a^2
+    for (int k = ty; k < nrows; k += 4) {
+        const size_t row = (size_t)(y0 + g.wy0 + k);
+        for (int cx = tx; cx < ncols; cx += 64) {
+            const int ca = xt + g.wx0 + cx + g.pad_a, cb = xt + g.wx0 + cx + g.boff + g.pad_b;
+            const uint32_t a = ca >= 0 && ca < g.pitch_a ? g.A[row * g.pitch_a + ca] : 0u;
+            const uint32_t b = cb >= 0 && cb < g.pitch_b ? g.B[row * g.pitch_b + cb] : 0u;
+            if constexpr (SSD) {
+                const uint32_t aa = pix_dot<CENTRED>(a, a, 0u);
+                e0[k][cx] = aa + pix_dot<CENTRED>(b, b, 0u) - 2u * pix_dot<CENTRED>(a, b, 0u); // (a-b)^2 >= 0
+                ea[k][cx] = aa;
+            } else {
+                e0[k][cx] = pix_sad(a, b, 0u);
+            }
+        }
+    }
+    __syncthreads();
+    // (2) horizontal window sums
+    for (int k = ty; k < nrows; k += 4) {
+        uint32_t s0 = 0, sa = 0;
+#pragma unroll 8
+        for (int i = 0; i < g.ww; ++i) {
+            s0 += e0[k][tx + i];
+            if constexpr (SSD) sa += ea[k][tx + i];
+        }
+        h0[k][tx] = s0;
+        if constexpr (SSD) ha[k][tx] = sa;
+    }
+    __syncthreads();
+    // (3) vertical sliding sums and the decision
+    const int x = xt + tx; // canonical (mirrored) column
+    const int seg = kBoxRows / 4;
+    const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
+    if (x >= g.ox1 || ya >= yb) return;
     const int xo = g.wa - 1 - x; // original column
-    float *o = g.out + (size_t)y * g.out_pitch + xo;
+    uint32_t c0 = 0, sa = 0;
+    for (int k = 0; k < g.wh; ++k) {
+        c0 += h0[ya - y0 + k][tx];
+        if constexpr (SSD) sa += ha[ya - y0 + k][tx];
+    }
+    const double area = (double)(g.ww * g.wh);
+    const int xb0 = x + g.boff; // target centre of d = 0
+    for (int y = ya; y < yb; ++y) {
+        float *o = g.out + (size_t)y * g.out_pitch + xo;
+        uint8_t code = kSelFixed;
+        float val = 0.0f;
+        if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] != (CENTRED ? kCentre : 0u)) {
+            if (!(g.d_hi >= 0 && xb0 >= g.b_lo)) {
+                val = -(float)xo; // no candidate at all
+            } else if (!(g.d_hi >= 1 && xb0 - 1 >= g.b_lo)) {
+                val = 0.0f; // d = 0 is the only candidate
+            } else {
+                val = *o; // the search's d >= 1 winner stays unless the recurrence says 0
+                const long long c1 = (long long)g.cost[(size_t)y * g.cost_pitch + xo] + (SSD ? (long long)sa : 0LL);
+                code = smooth_code<SSD>((long long)c0, c1, area, g.s);
+            }
+        }
+        *o = val;
+        if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
+        g.sel[(size_t)y * g.sel_pitch + xo] = code;
+        const int k = y - y0;
+        if (y + 1 < yb) {
+            c0 += h0[k + g.wh][tx] - h0[k][tx];
+            if constexpr (SSD) sa += ha[k + g.wh][tx] - ha[k][tx];
+        }
+    }
+}
+
+template <bool SSD, bool CENTRED>
+__global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const PreparePlanesArgs g)
+{
+    GenericArgs e{}; // only the skip rectangle is used by ring_pixel
+    e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
+    int x, y; // original coordinates
+    if (!ring_pixel(e, g.wa, g.ha, (long long)blockIdx.x * blockDim.x + threadIdx.x, &x, &y)) return;
+    const int xm = g.wa - 1 - x;
+    float *o = g.out + (size_t)y * g.out_pitch + x;
     uint8_t code = kSelFixed;
     float val = 0.0f;
-    if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] != (CENTRED ? kCentre : 0u)) {
-        const int xb0 = x + g.boff; // target centre of d = 0
-        if (!(g.d_hi >= 0 && xb0 >= g.b_lo)) {
-            val = -(float)xo; // no candidate at all
-        } else if (!(g.d_hi >= 1 && xb0 - 1 >= g.b_lo)) {
+    if (y < g.height && g.A[(size_t)y * g.pitch_a + xm + g.pad_a] != (CENTRED ? kCentre : 0u)) {
+        const int left = min(x, g.half), right = min(g.wa - x - 1, g.half);
+        const int up = min(y, g.half), down = min(g.ha - y - 1, g.half);
+        const int ww = left + right, wh = up + down;
+        const bool any = ww > 0 && wh > 0 && g.max_d > 0 && x + right < g.wb;
+        if (!any) {
+            val = -(float)x; // no candidate at all: stores -x (BlockSearch.cpp:174)
+        } else if (!(g.max_d > 1 && x + 1 + right < g.wb)) {
             val = 0.0f; // d = 0 is the only candidate
         } else {
-            const int d1 = (int)*o;
-            long long c0 = 0, c1 = 0;
-            for (int r = 0; r < g.wh; ++r) {
-                const uint32_t *pa = g.A + (size_t)(y + g.wy0 + r) * g.pitch_a + (x + g.wx0 + g.pad_a);
-                const uint32_t *p0 = g.B + (size_t)(y + g.wy0 + r) * g.pitch_b + (xb0 + g.wx0 + g.pad_b);
-                const uint32_t *p1 = p0 - d1;
-                uint32_t aa = 0, b0 = 0, b1 = 0, ab0 = 0, ab1 = 0;
-                for (int i = 0; i < g.ww; ++i) {
-                    const uint32_t a = pa[i], v0 = p0[i], v1 = p1[i];
+            const int ca = xm - right + 1; // first window column, canonical
+            long long c0 = 0, sa = 0;
+            for (int r = y - up; r < y + down; ++r) {
+                const uint32_t *pa = g.A + (size_t)r * g.pitch_a + ca + g.pad_a;
+                const uint32_t *pb = g.B + (size_t)r * g.pitch_b + ca + g.boff + g.pad_b;
+                uint32_t aa = 0, bb = 0, ab = 0;
+                for (int i = 0; i < ww; ++i) {
                     if constexpr (SSD) {
-                        aa = pix_dot<CENTRED>(a, a, aa);
-                        b0 = pix_dot<CENTRED>(v0, v0, b0);
-                        b1 = pix_dot<CENTRED>(v1, v1, b1);
-                        ab0 = pix_dot<CENTRED>(a, v0, ab0);
-                        ab1 = pix_dot<CENTRED>(a, v1, ab1);
+                        aa = pix_dot<CENTRED>(pa[i], pa[i], aa);
+                        bb = pix_dot<CENTRED>(pb[i], pb[i], bb);
+                        ab = pix_dot<CENTRED>(pa[i], pb[i], ab);
                     } else {
-                        ab0 = pix_sad(a, v0, ab0);
-                        ab1 = pix_sad(a, v1, ab1);
+                        ab = pix_sad(pa[i], pb[i], ab);
                     }
                 }
-                if constexpr (SSD) { // sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab, row by row in 32 bits
-                    c0 += (long long)(int32_t)aa + (int32_t)b0 - 2LL * (int32_t)ab0;
-                    c1 += (long long)(int32_t)aa + (int32_t)b1 - 2LL * (int32_t)ab1;
+                if constexpr (SSD) {
+                    c0 += (long long)(int32_t)aa + (int32_t)bb - 2LL * (int32_t)ab;
+                    sa += (int32_t)aa;
                 } else {
-                    c0 += ab0;
-                    c1 += ab1;
+                    c0 += ab;
                 }
             }
-            const double area = (double)(g.ww * g.wh);
-            const double e1 = (SSD ? sqrt((double)c1) : (double)c1) / area;
-            double e0 = (SSD ? sqrt((double)c0) : (double)c0) / area;
-            code = 0;
-            if (e1 < e0) code |= 1;
-            e0 *= g.s;
-            if (e1 < e0) code |= 2;
-            e0 *= g.s;
-            if (e1 < e0) code |= 4;
-            val = (float)d1;
+            val = *o;
+            const long long c1 = (long long)g.cost[(size_t)y * g.cost_pitch + x] + sa;
+            code = smooth_code<SSD>(c0, c1, (double)(ww * wh), g.s);
         }
     }
     *o = val;
     if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
-    g.sel[(size_t)y * g.sel_pitch + xo] = code;
+    g.sel[(size_t)y * g.sel_pitch + x] = code;
 }
 
 // compose two maps {0,1}->{0,1} stored as bit0 = f(0), bit1 = f(1):  (b o a)(v) = b(a(v))
@@ -849,26 +941,39 @@ size_t smooth_planes_bytes(int w, int h)
 }
 
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
-                         const Canon *canon, Plane pa, Plane pb, hipStream_t st)
+                         const Canon *canon, Plane pa, Plane pb, const int32_t *cost, int cost_pitch, hipStream_t st)
 {
-    dim3 grid(ceil_div(g.w2, 256), g.h2);
-    if (canon) { // right view with a marching interior: its pixels on the planes, the ring on bytes
+    if (canon) { // right view after the marching kernel: everything on the packed planes + the cost plane
         PreparePlanesArgs a{};
         a.A = pa.data; a.B = pb.data;
         a.pitch_a = pa.pitch; a.pad_a = pa.pad; a.pitch_b = pb.pitch; a.pad_b = pb.pad;
-        a.wa = canon->wa; a.ww = canon->ww; a.wh = canon->wh; a.wx0 = canon->wx0; a.wy0 = canon->wy0;
+        a.wa = canon->wa; a.ha = canon->ha; a.wb = canon->wb; a.height = std::min(canon->ha, canon->hb);
+        a.half = canon->wh / 2; a.max_d = g.max_d;
+        a.ww = canon->ww; a.wh = canon->wh; a.wx0 = canon->wx0; a.wy0 = canon->wy0;
         a.boff = canon->boff; a.d_hi = g.max_d - 1; a.b_lo = canon->b_lo;
         a.ox0 = canon->ox0; a.ox1 = canon->ox1; a.oy0 = canon->oy0; a.oy1 = canon->oy1;
-        a.s = s; a.out = g.out; a.out_pitch = g.out_pitch; a.sel = sel; a.sel_pitch = sel_pitch;
-        dim3 gi(ceil_div(canon->ox1 - canon->ox0, 256), canon->oy1 - canon->oy0);
-        if (!canon->ssd)
-            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<false, false>), gi, dim3(256), 0, st, a);
-        else if (march_centred(*canon))
-            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<true, true>), gi, dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL((ws_smooth_prepare_planes_kernel<true, false>), gi, dim3(256), 0, st, a);
+        a.skip_x0 = g.skip_x0; a.skip_x1 = g.skip_x1; a.skip_y0 = g.skip_y0; a.skip_y1 = g.skip_y1;
+        a.s = s; a.out = g.out; a.out_pitch = g.out_pitch; a.cost = cost; a.cost_pitch = cost_pitch;
+        a.sel = sel; a.sel_pitch = sel_pitch;
+        if (!cost || canon->ww > kBoxMaxW || canon->wh > kBoxMaxW) return hipErrorInvalidValue;
+        dim3 gi(ceil_div(canon->ox1 - canon->ox0, 64), ceil_div(canon->oy1 - canon->oy0, kBoxRows));
+        const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
+        const long long nring = (long long)canon->wa * canon->ha - (inside > 0 ? inside : 0);
+        dim3 gr((unsigned)ceil_div((int)nring, 256));
+        if (!canon->ssd) {
+            hipLaunchKernelGGL((ws_smooth_prepare_box_kernel<false, false>), gi, dim3(256), 0, st, a);
+            if (nring > 0) hipLaunchKernelGGL((ws_smooth_prepare_ring_kernel<false, false>), gr, dim3(256), 0, st, a);
+        } else if (march_centred(*canon)) {
+            hipLaunchKernelGGL((ws_smooth_prepare_box_kernel<true, true>), gi, dim3(256), 0, st, a);
+            if (nring > 0) hipLaunchKernelGGL((ws_smooth_prepare_ring_kernel<true, true>), gr, dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((ws_smooth_prepare_box_kernel<true, false>), gi, dim3(256), 0, st, a);
+            if (nring > 0) hipLaunchKernelGGL((ws_smooth_prepare_ring_kernel<true, false>), gr, dim3(256), 0, st, a);
+        }
+    } else {
+        dim3 grid(ceil_div(g.w2, 256), g.h2);
+        hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
     }
-    hipLaunchKernelGGL(ws_smooth_prepare_kernel, grid, dim3(256), 0, st, g, s, sel, sel_pitch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int rows = std::min(g.h1, g.h2);
