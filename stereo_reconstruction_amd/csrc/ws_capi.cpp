@@ -307,7 +307,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         const int keys_pitch = (c.wa + 15) & ~15;
         if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
         int32_t *cost_out = nullptr; // the smoothFactor passes of the right view want the winners' costs
-        if (ctx->want_cost) {
+        if (ctx->want_cost && march_has_cost(c)) {
             if ((rc = ensure(ctx, ctx->cost, (size_t)c.wa * c.ha * 4)) != WS_OK) return rc;
             cost_out = static_cast<int32_t *>(ctx->cost.p);
         }

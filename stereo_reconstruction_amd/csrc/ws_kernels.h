@@ -68,6 +68,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
                         float *out, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
                         hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2)
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
+bool march_has_cost(const Canon &c); // is there an instantiation that also writes cost_out?
 
 // Brute-force kernels on the original 8-bit images (original coordinates, literal rules).
 struct GenericArgs {

@@ -166,7 +166,7 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
     }
 }
 
-template <int X, int ND, int WW, int WH, bool SSD, int MAXT>
+template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
     static_assert(X % 4 == 0 && ND % 4 == 0, "runs start on 16-byte quads");
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
                     if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
                     g.out[(size_t)y * g.out_pitch + xo] = val;
-                    if (g.cost_out && key != kEmpty) {
+                    if (COST && key != kEmpty) { // (a template flag: the test alone cost the hot kernel 2.7 %)
                         int32_t cst;
                         if constexpr (SSD) cst = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
                         else cst = (int32_t)key >> g.tag_bits;
@@ -370,17 +370,24 @@ typedef void (*MarchFn)(const MarchArgs);
 struct MarchEntry {
     int ww, wh, ssd;
     MarchFn fn;
+    MarchFn fn_cost; // the same kernel also writing the winners' costs (right-view window sizes only)
     const char *name;
 };
-#define WS_MARCH_ENTRY(W, H)                                                                     \
-    {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, "ws_march_kernel<sad," #W "x" #H ">"}, \
-    {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, "ws_march_kernel<ssd," #W "x" #H ">"}
+#define WS_MARCH_ENTRY(W, H)                                                                              \
+    {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H ">"}, \
+    {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H ">"}
+#define WS_MARCH_ENTRY_COST(W, H)                                                                      \
+    {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, ws_march_kernel<kX, kND, W, H, false, kMaxT, true>, \
+     "ws_march_kernel<sad," #W "x" #H ">"},                                                            \
+    {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, ws_march_kernel<kX, kND, W, H, true, kMaxT, true>, \
+     "ws_march_kernel<ssd," #W "x" #H ">"}
 static const MarchEntry kMarchTable[] = {
-    // left view: bs x bs                       right view: (bs-1) x (bs-1)
+    // left view: bs x bs
     WS_MARCH_ENTRY(3, 3), WS_MARCH_ENTRY(5, 5), WS_MARCH_ENTRY(7, 7), WS_MARCH_ENTRY(9, 9),
     WS_MARCH_ENTRY(11, 11), WS_MARCH_ENTRY(13, 13), WS_MARCH_ENTRY(15, 15), WS_MARCH_ENTRY(17, 17),
-    WS_MARCH_ENTRY(2, 2), WS_MARCH_ENTRY(4, 4), WS_MARCH_ENTRY(6, 6), WS_MARCH_ENTRY(8, 8),
-    WS_MARCH_ENTRY(10, 10), WS_MARCH_ENTRY(12, 12), WS_MARCH_ENTRY(14, 14), WS_MARCH_ENTRY(16, 16),
+    // right view: (bs-1) x (bs-1)
+    WS_MARCH_ENTRY_COST(2, 2), WS_MARCH_ENTRY_COST(4, 4), WS_MARCH_ENTRY_COST(6, 6), WS_MARCH_ENTRY_COST(8, 8),
+    WS_MARCH_ENTRY_COST(10, 10), WS_MARCH_ENTRY_COST(12, 12), WS_MARCH_ENTRY_COST(14, 14), WS_MARCH_ENTRY_COST(16, 16),
 };
 
 static const MarchEntry *find_march(const Canon &c)
@@ -395,6 +402,12 @@ static int tag_bits_for(const Canon &c)
     int bits = 1;
     while ((1 << bits) < c.d_hi - c.d_lo + 1) ++bits;
     return bits;
+}
+
+bool march_has_cost(const Canon &c)
+{
+    const MarchEntry *e = find_march(c);
+    return e && e->fn_cost;
 }
 
 int march_centred(const Canon &c) { return c.ssd && ssd_needs_centring(c.ww, c.wh, kND); }
@@ -548,8 +561,10 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.prefer_large = c.prefer_large;
     g.mirror = c.mirror;
     g.fallback_neg = c.fallback_neg;
+    const MarchFn fn = cost_out ? e->fn_cost : e->fn;
+    if (!fn) return hipErrorInvalidValue;
     if (m.lds_bytes > 48 * 1024) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->fn),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)m.lds_bytes);
         if (err != hipSuccess) return err;
@@ -562,7 +577,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     for (int pass = 0; pass < m.passes; ++pass) {
         g.d_first = c.d_lo + pass * m.nch * m.nd_per_thread;
         g.pass_mode = m.passes == 1 ? 0 : pass == 0 ? 1 : pass == m.passes - 1 ? 3 : 2;
-        hipLaunchKernelGGL(e->fn, grid, dim3(m.threads), m.lds_bytes, s, g);
+        hipLaunchKernelGGL(fn, grid, dim3(m.threads), m.lds_bytes, s, g);
     }
     return hipGetLastError();
 }

@@ -856,12 +856,14 @@ __global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__
     const int y = blockIdx.y;
     const uint32_t c = x < w ? sel[(size_t)y * sel_pitch + x] : kSelFixed; // beyond the row: fixed, non-zero
     const bool fixed = c & kSelFixed;
-    const unsigned long long t0 = __ballot(!fixed && (c & 1)), t1 = __ballot(!fixed && (c & 2)),
-                             t2 = __ballot(!fixed && (c & 4)), fx = __ballot(fixed),
-                             zf = __ballot(fixed && (c & kSelZero));
+    // n_k = "this pixel is 0 when k of its two neighbours are": !t_k for a free pixel, the fixed value's
+    // zero flag otherwise (the planes the resolver selects from with the upper neighbour's flags)
+    const bool zf = fixed && (c & kSelZero);
+    const unsigned long long n0 = __ballot(fixed ? zf : !(c & 1)), n1 = __ballot(fixed ? zf : !(c & 2)),
+                             n2 = __ballot(fixed ? zf : !(c & 4));
     if ((threadIdx.x & 63) == 0 && (x >> 6) < nwp) {
-        unsigned long long *row = planes + (size_t)y * 5 * nwp + (x >> 6);
-        row[0] = t0; row[nwp] = t1; row[2 * nwp] = t2; row[3 * nwp] = fx; row[4 * nwp] = zf;
+        unsigned long long *row = planes + (size_t)y * 3 * nwp + (x >> 6);
+        row[0] = n0; row[nwp] = n1; row[2 * nwp] = n2;
     }
 }
 
@@ -874,14 +876,23 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const unsign
     extern __shared__ uint4 ws_smem4[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
     const int lane = threadIdx.x;
-    const int row_bytes = 5 * nwp * 8; // nwp is even: a multiple of 16 bytes
+    const int row_bytes = 3 * nwp * 8; // nwp is even: a multiple of 16 bytes
     const int chunk_bytes = chunk_rows * row_bytes;
     const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
     const uint8_t *src0 = reinterpret_cast<const uint8_t *>(planes);
     for (int o = lane * 16; o < chunk_bytes; o += 1024)
         __builtin_amdgcn_global_load_lds((glb_void *)(src0 + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
     unsigned long long zprev = 0;
+    // Branch-free rows: lanes beyond the image's words read a zeroed quadword behind the two chunks
+    // with stride 0 and store to a scratch quadword behind the resolved plane.
     const bool active = lane < nwp;
+    unsigned long long *zero_q = reinterpret_cast<unsigned long long *>(lds + 2 * chunk_bytes);
+    if (lane == 0) zero_q[0] = 0ull;
+    const int lstride = active ? 3 * nwp : 0; // in quadwords
+    unsigned long long *zp = active ? zplane + lane : zplane + (size_t)rows * nwp;
+    const int zstride = active ? nwp : 0;
+    // this lane's bit in a 64-bit scalar mask, as two halves
+    const uint32_t mlo = lane < 32 ? 1u << lane : 0u, mhi = lane >= 32 ? 1u << (lane - 32) : 0u;
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint8_t *cur = lds + (c & 1) * chunk_bytes;
@@ -892,31 +903,30 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const unsign
                 __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
         }
         const int y_end = min((c + 1) * chunk_rows, rows);
+        const unsigned long long *row = active ? reinterpret_cast<const unsigned long long *>(cur) + lane : zero_q;
+        const int off_b = active ? nwp : 0, off_c = active ? 2 * nwp : 0;
+        // the next row's planes are read ahead of the chain through zprev (the row after a chunk's last
+        // one is read too, and dropped: it is inside the other chunk or the zero quadword's padding)
+        unsigned long long a = row[0], b = row[off_b], cc = row[off_c];
         for (int y = c * chunk_rows; y < y_end; ++y) {
-            const unsigned long long *row = reinterpret_cast<const unsigned long long *>(cur + (size_t)(y - c * chunk_rows) * row_bytes);
-            unsigned long long g = 0, p = 0;
-            if (active) {
-                const unsigned long long t0 = row[lane], t1 = row[nwp + lane], t2 = row[2 * nwp + lane],
-                                         fx = row[3 * nwp + lane], zf = row[4 * nwp + lane];
-                // zero when the left neighbour is not / is zero, given the upper neighbour's flag
-                unsigned long long n0 = ~((t0 & ~zprev) | (t1 & zprev)), n1 = ~((t1 & ~zprev) | (t2 & zprev));
-                n0 = (n0 & ~fx) | zf;
-                n1 = (n1 & ~fx) | zf;
-                g = n0 & n1;
-                p = n1 & ~n0;
-            }
-            const unsigned long long A = g | p, B = g, S0 = A + B;
-            const bool cout0 = S0 < A, cout1 = cout0 || S0 == ~0ull;
+            row += lstride;
+            const unsigned long long na = row[0], nb = row[off_b], nc = row[off_c];
+            // zero when the left neighbour is not / is zero, given the upper neighbour's flag
+            const unsigned long long n0 = (a & ~zprev) | (b & zprev), n1 = (b & ~zprev) | (cc & zprev);
+            // generate = n0 & n1, propagate = n1 & ~n0: the adder's operands are A = g | p = n1, B = g
+            const unsigned long long A = n1, B = n0 & n1, S0 = A + B;
             // carries between the lanes' words: the same adder on the ballots (scalar unit)
-            const unsigned long long gw = __ballot(cout0), pw = __ballot(cout1 && !cout0);
-            const unsigned long long aw = gw | pw, sw = aw + gw, cw = sw ^ aw ^ gw; // bit l = carry into lane l
-            const unsigned long long cin = (cw >> lane) & 1ull; // column 0 of the row: no left neighbour
-            const unsigned long long S = S0 + cin;
+            const unsigned long long gw = __builtin_amdgcn_ballot_w64(S0 < A), fw = __builtin_amdgcn_ballot_w64(S0 == ~0ull);
+            const unsigned long long aw = gw | fw, sw = aw + gw, cw = sw ^ aw ^ gw; // bit l = carry into lane l
+            const bool cin = (((uint32_t)cw & mlo) | ((uint32_t)(cw >> 32) & mhi)) != 0; // column 0 of the row: no left neighbour
+            const unsigned long long S = S0 + (cin ? 1ull : 0ull);
             const unsigned long long carries = S ^ A ^ B; // bit k = carry into column k
-            const unsigned long long cout = cin ? (unsigned long long)cout1 : (unsigned long long)cout0;
-            const unsigned long long z = (carries >> 1) | (cout << 63);
-            if (active) zplane[(size_t)y * nwp + lane] = z;
+            const bool cout = S0 < A || (cin && S0 == ~0ull);
+            const unsigned long long z = (carries >> 1) | (cout ? 1ull << 63 : 0ull);
+            *zp = z;
+            zp += zstride;
             zprev = z;
+            a = na; b = nb; cc = nc;
         }
     }
 }
@@ -937,7 +947,7 @@ int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
 size_t smooth_planes_bytes(int w, int h)
 {
     const int nwp = round_up(ceil_div(w, 64), 2);
-    return (size_t)(h + 64) * 6 * nwp * 8; // 5 code planes + the resolved plane
+    return (size_t)(h + 64) * 4 * nwp * 8; // 3 code planes + the resolved plane
 }
 
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
@@ -980,13 +990,13 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
     const int nwords = ceil_div(g.w2, 64);
     if (s >= 0.0 && s <= 1.0 && nwords <= 64 && planes) {
         const int nwp = round_up(nwords, 2);
-        unsigned long long *zplane = planes + (size_t)(g.h2 + 64) * 5 * nwp;
+        unsigned long long *zplane = planes + (size_t)(g.h2 + 64) * 3 * nwp;
         hipLaunchKernelGGL(ws_smooth_planes_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, sel, sel_pitch,
                            g.w2, planes, nwp);
-        int chunk = 24576 / (5 * nwp * 8);
+        int chunk = 24576 / (3 * nwp * 8);
         if (chunk > 64) chunk = 64;
         if (chunk < 1) chunk = 1;
-        hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel, dim3(1), dim3(64), (size_t)2 * chunk * 5 * nwp * 8, st, planes,
+        hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel, dim3(1), dim3(64), (size_t)2 * chunk * 3 * nwp * 8 + 3 * nwp * 8 + 64, st, planes,
                            nwp, rows, zplane, chunk);
         hipLaunchKernelGGL(ws_smooth_apply_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch,
                            g.w2, rows, sel, sel_pitch, zplane, nwp);
