@@ -308,6 +308,52 @@ def test_strided_buffers_and_extreme_arguments(wslib, gpu_ctx, oracle):
     assert e.value.code == -1
 
 
+def test_very_wide_and_very_tall_images(wslib, gpu_ctx, oracle):
+    """More than 4096 columns / rows: many tiles per row, many strips per column, 16-bit-looking sizes."""
+    left, right, _ = make_pair(5000, 96, 90, seed=81)
+    for view, bs, cost in (("left", 5, "ssd"), ("right", 5, "sad"), ("right", 9, "ssd")):
+        got = run(wslib, gpu_ctx, view, left, right, bs, 0, 96, cost)
+        assert np.array_equal(got, ref(oracle, view, left, right, bs, 0, 96, cost)), (view, bs, cost)
+    left, right, _ = make_pair(96, 4500, 40, seed=82)
+    for view, bs, cost in (("left", 7, "sad"), ("right", 7, "ssd")):
+        got = run(wslib, gpu_ctx, view, left, right, bs, 0, 40, cost)
+        assert np.array_equal(got, ref(oracle, view, left, right, bs, 0, 40, cost)), (view, bs, cost)
+    # the right view's smoothFactor passes on a map wider than 64 words of 64 columns
+    got = wslib.BlockSearch(left, right, 7, 0, 40, context=gpu_ctx).computeDisparityMapRight(0.9)
+    assert np.array_equal(got, oracle.block_right(left, right, 7, 0, 40, smooth=0.9))
+    wl, wr, _ = make_pair(4300, 40, 30, seed=83)
+    got = wslib.BlockSearch(wl, wr, 5, 0, 30, context=gpu_ctx).computeDisparityMapRight(0.9)
+    assert np.array_equal(got, oracle.block_right(wl, wr, 5, 0, 30, smooth=0.9))
+
+
+def test_two_contexts_from_two_threads(wslib, oracle):
+    """One context per host thread on the same device: no shared state."""
+    import threading
+    left, right, _ = make_pair(400, 120, 48, seed=84)
+    want = {"left": oracle.block_left(left, right, 7, 0, 48, threads=4),
+            "right": oracle.block_right(left, right, 7, 0, 48, threads=4)}
+    errors = []
+
+    def work(view):
+        try:
+            ctx = wslib.WindowSearch(0)
+            b = wslib.BlockSearch(left, right, 7, 0, 48, context=ctx)
+            for _ in range(20):
+                got = b.computeDisparityMapLeft(1.0) if view == "left" else b.computeDisparityMapRight(1.0)
+                if not np.array_equal(got, want[view]):
+                    errors.append(view)
+                    return
+        except Exception as e:          # noqa: BLE001 - reported through the list
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(v,)) for v in ("left", "right", "left", "right")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
