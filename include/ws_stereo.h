@@ -76,8 +76,8 @@ typedef struct {
     int block_size;       /* blockSize (LINEAR ignores it) */
     int min_disparity;    /* minDisparity: read by the right view only (BlockSearch.cpp:147) */
     int max_disparity;    /* maxDisparity: left tries d = maxD..1, right d = minD..maxD-1 */
-    double smooth_factor; /* smoothFactor, any value but NaN; != 1 in the left view (a true raster-order
-                             dependency) is limited to images of <= 4096 columns */
+    double smooth_factor; /* smoothFactor, any value but NaN (!= 1 in the left view is a true raster-order
+                             dependency, SURVEY.md 8f-1: a serial pass of a few ms) */
     int var_block;        /* varBlock (right view): grow the window while its centred norm < thres */
     double thres;         /* thres for varBlock, default 19.0 (BlockSearch.h:37) */
     int subpixel;         /* extension: parabolic refinement on the aggregated integer cost */

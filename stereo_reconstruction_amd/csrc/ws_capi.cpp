@@ -36,7 +36,7 @@ struct Job { // one pair in flight on the batched host path
     bool busy = false;
 };
 
-std::string g_create_error;
+thread_local std::string g_create_error; // ws_last_error(NULL): why the last ws_create on this thread failed
 
 } // namespace
 
@@ -109,8 +109,6 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
     if (p->view != WS_VIEW_LINEAR && (p->block_size < 1 || p->block_size > 63))
         return fail(ctx, WS_ERR_ARG, "blockSize %d outside [1,63]", p->block_size);
     if (p->view == WS_VIEW_LINEAR && p->linear_range < 1) return fail(ctx, WS_ERR_ARG, "linear_range < 1");
-    if (p->view == WS_VIEW_LEFT && p->smooth_factor != 1.0 && L->width > 4096)
-        return fail(ctx, WS_ERR_UNSUPPORTED, "smoothFactor != 1 in the left view: images up to 4096 columns");
     if (!(p->smooth_factor == p->smooth_factor)) return fail(ctx, WS_ERR_ARG, "smoothFactor is NaN");
     if (p->var_block && p->view == WS_VIEW_RIGHT && p->subpixel)
         return fail(ctx, WS_ERR_UNSUPPORTED, "sub-pixel refinement together with varBlock");
@@ -197,11 +195,9 @@ int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ga.view = p->view; ga.ssd = p->cost == WS_COST_SSD;
         ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
         ga.out = out; ga.out_pitch = out_stride;
-        uint32_t *top3 = nullptr;
-        if (p->smooth_factor > 1.0 || p->smooth_factor < 0.0) { // the three best candidates per pixel
-            if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
-            top3 = static_cast<uint32_t *>(ctx->top3.p);
-        }
+        // per pixel the best candidate's cost (0 <= s <= 1) or the three best candidates
+        if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
+        uint32_t *top3 = static_cast<uint32_t *>(ctx->top3.p);
         WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march ? &ctx->last_canon : nullptr,
                                        ctx->last_pa, ctx->last_pb, s));
         return WS_OK;

@@ -412,15 +412,22 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, 
 }
 
 // ------------------------------------------------------------------------------------------
-// smoothFactor in [0,1) for the LEFT view (BlockSearch.cpp:68-73): there the factor reaches any
+// smoothFactor != 1 for the LEFT view (BlockSearch.cpp:68-73): there the factor reaches any
 // candidate d that equals the upper / left neighbour's stored value -- a true dependency on the
-// neighbours' values in raster order.  With 0 <= s <= 1 a discounted candidate only gets cheaper,
-// so the winner is always one of { d1 = the undiscounted argmin, up, left } (every other d is no
-// better than d1 and loses the tie by the reference's own rule).  So: the ordinary data-parallel
-// search gives d1; one workgroup then walks the rows in order and, inside a row, iterates
-//     v_x <- F_x(v_{x-1})          F_x(l) = lexmin over {d1, up, l} of (distance * s^matches, -d)
-// from the left-independent guess until nothing changes (the fixed point is the sequential
-// result; the iteration count is the longest run a left neighbour's value actually propagates).
+// neighbours' values in raster order.  Only those two candidates are ever touched, so:
+//   * 0 <= s <= 1: a discounted candidate only gets cheaper, the winner is one of
+//     { d1 = the undiscounted argmin, up, left } (every other d is no better than d1 and loses the
+//     tie by the reference's own rule).  The ordinary data-parallel search gives d1.
+//   * any other s can make a candidate DEARER: the winner is up, left or one of the THREE best
+//     untouched candidates in the reference's order (cost ascending, then d descending), kept per
+//     pixel by ws_left_top3_kernel.  For s >= 1 an unlisted neighbour value cannot win at all.
+// Pixel (y, x) needs (y-1, x) and (y, x-1): all pixels of an anti-diagonal x + y = k are
+// independent.  One workgroup, thread t = row, walks the diagonals (ws_smooth_left_wave_kernel):
+// the upper neighbour's value arrives through LDS from thread t-1 one step earlier, the left one is
+// the thread's own previous result, and the window distance of a neighbour's value is a SLIDING
+// sum along the row (the winner's cost at x-1 plus one window column entering, one leaving), so a
+// step costs O(bs) pixel operations, not O(bs^2).  No iteration, any image width; rows in bands
+// of 1024.
 // ------------------------------------------------------------------------------------------
 struct SmoothLeftArgs {
     const uint8_t *L;
@@ -525,134 +532,7 @@ __device__ __forceinline__ bool left_better(double dist, int d, double bdist, in
     return dist < bdist || (dist == bdist && d > bd);
 }
 
-constexpr int kSmoothLeftPer = 4; // columns per thread: images up to 4096 wide
-
-constexpr uint32_t kCostUnknown = 0xffffffffu; // published beside a value whose window distance is not known
-
-__global__ void __launch_bounds__(1024) ws_smooth_left_kernel(const SmoothLeftArgs g)
-{
-    // [3][w1] floats: previous row, current guess, next guess; [2][w1] integer window costs of the
-    // guesses (cost of (x, cur[x])): x+1 slides them by one column instead of summing a whole window
-    extern __shared__ float sl_rows[];
-    __shared__ int changed[3];
-    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
-    uint32_t *ccur = reinterpret_cast<uint32_t *>(sl_rows + 3 * g.w1), *cnxt = ccur + g.w1;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int half = (g.block_size - 1) / 2;
-    const int height = min(g.h1, g.h2);
-    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f; // row above the first interior row: border zeros
-    if (half > 0) // (for half == 0 the first row has no upper neighbour at all: zeros never match d >= 1)
-        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
-    __syncthreads();
-    for (int y = half; y < height - half; ++y) {
-        float *orow = g.out + (size_t)y * g.out_pitch;
-        // per column: the fixed ingredients of F_x
-        int d1[kSmoothLeftPer], du[kSmoothLeftPer], lastl[kSmoothLeftPer];
-        uint32_t c1[kSmoothLeftPer], cu[kSmoothLeftPer], cl[kSmoothLeftPer];
-        double u1[kSmoothLeftPer], uu[kSmoothLeftPer];
-        bool act[kSmoothLeftPer];
-#pragma unroll
-        for (int k = 0; k < kSmoothLeftPer; ++k) {
-            const int x = tid + k * nt;
-            act[k] = false;
-            d1[k] = du[k] = 0; lastl[k] = -1;
-            c1[k] = cu[k] = cl[k] = 0;
-            u1[k] = uu[k] = 0.0;
-            if (x < g.w1) {
-                const float v = orow[x];
-                cur[x] = v;
-                ccur[x] = kCostUnknown;
-                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
-                    const int d = (int)v;
-                    if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, value x stays
-                        act[k] = true;
-                        d1[k] = d;
-                        c1[k] = left_cost_int(g, x, y, d, half);
-                        u1[k] = left_dist_of(g, c1[k]);
-                        const int up = (int)prev[x];
-                        const bool up_int = (float)up == prev[x];
-                        if (y >= 1 && up_int && up != d && left_candidate_ok(g, x, up, half)) {
-                            du[k] = up;
-                            cu[k] = left_cost_int(g, x, y, up, half);
-                            uu[k] = left_dist_of(g, cu[k]) * g.s;
-                        } else if (y >= 1 && up_int && up == d) {
-                            du[k] = -1; // d1 itself is the upper neighbour's value
-                            u1[k] *= g.s;
-                        }
-                        // the guess without a left neighbour
-                        const bool take_up = du[k] > 0 && left_better(uu[k], du[k], u1[k], d);
-                        cur[x] = take_up ? (float)du[k] : (float)d;
-                        ccur[x] = take_up ? cu[k] : c1[k];
-                    }
-                }
-            }
-        }
-        if (tid < 3) changed[tid] = 0;
-        __syncthreads();
-        // one barrier per iteration: guesses are double-buffered and the "changed" flag rotates over
-        // three slots (slot it+2 is cleared while slot it is read and slot it+1 may already be set)
-        for (int it = 0; it < g.w1 + 1; ++it) {
-            const int slot = it % 3;
-#pragma unroll
-            for (int k = 0; k < kSmoothLeftPer; ++k) {
-                const int x = tid + k * nt;
-                if (x >= g.w1) continue;
-                float res = cur[x];
-                uint32_t rc = ccur[x];
-                if (act[k]) {
-                    // start from d1 (its upper-neighbour factor already in u1), then up, then left
-                    double bdist = u1[k];
-                    int bd = d1[k];
-                    rc = c1[k];
-                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
-                    const int l = (int)lf;
-                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
-                    if (l_ok && l == d1[k]) bdist = bdist * g.s; // the left factor comes second (BlockSearch.cpp:71-73)
-                    if (du[k] > 0) {
-                        double e = uu[k];
-                        if (l_ok && l == du[k]) e = e * g.s;
-                        if (left_better(e, du[k], bdist, bd)) { bdist = e; bd = du[k]; rc = cu[k]; }
-                    }
-                    if (l_ok && l != d1[k] && l != du[k]) {
-                        if (lastl[k] != l) { // distance at the left neighbour's value: cached per column
-                            const uint32_t cprev = ccur[x - 1]; // the window of (x-1, l), one column to the left
-                            if (cprev != kCostUnknown && g.block_size > 2)
-                                cl[k] = cprev + left_col_cost(g, x + half, y, l, half) - left_col_cost(g, x - 1 - half, y, l, half);
-                            else
-                                cl[k] = left_cost_int(g, x, y, l, half);
-                            lastl[k] = l;
-                        }
-                        const double e = left_dist_of(g, cl[k]) * g.s;
-                        if (left_better(e, l, bdist, bd)) { bdist = e; bd = l; rc = cl[k]; }
-                    }
-                    res = (float)bd;
-                }
-                nxt[x] = res;
-                cnxt[x] = rc;
-                if (res != cur[x]) changed[slot] = 1;
-            }
-            __syncthreads();
-            { float *t = cur; cur = nxt; nxt = t; }
-            { uint32_t *t = ccur; ccur = cnxt; cnxt = t; }
-            const int any = changed[slot];
-            if (tid == 0) changed[(it + 2) % 3] = 0;
-            if (!any) break;
-        }
-        for (int x = tid; x < g.w1; x += nt) {
-            orow[x] = cur[x];
-        }
-        __syncthreads();
-        { float *t = prev; prev = cur; cur = t; }
-    }
-}
-
-// ---- any other smoothFactor (s > 1, s < 0) in the left view ------------------------------------
-// A factor that can make a candidate DEARER breaks the {d1, up, left} argument above, but only two
-// candidates (the neighbours' values) are ever touched, so the winner is the upper / left
-// neighbour's value or one of the THREE best untouched candidates in the reference's own order
-// (cost ascending, then d descending).  ws_left_top3_kernel keeps those three per pixel (one
-// thread per pixel, d descending like BlockSearch.cpp:53, strict '<'); the raster pass below is
-// the same row walk / fixed-point iteration as above with F_x taken over {t0, t1, t2, up, left}.
+// the three best candidates of a pixel: (cost, d) x 3, kTopNone = no such candidate
 constexpr uint32_t kTopNone = 0xffffffffu; // above any window cost (63 * 63 * 3 * 255^2 < 2^30)
 
 __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
@@ -693,118 +573,235 @@ struct LeftBest {
     }
 };
 
-constexpr int kSmoothLeftGenPer = 4;
-
-__global__ void __launch_bounds__(1024) ws_smooth_left_general_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
-                                                                     int top_pitch)
+// 0 <= s <= 1 needs only the best candidate: d1 is in the map, its cost is summed here (all CUs),
+// in the layout of the top-3 buffer
+__global__ void __launch_bounds__(256) ws_left_cost_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
 {
-    extern __shared__ float sl_rows[]; // [3][w1]: previous row, current guess, next guess
-    __shared__ int changed[3];
-    float *prev = sl_rows, *cur = sl_rows + g.w1, *nxt = sl_rows + 2 * g.w1;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int half = (g.block_size - 1) / 2;
+    const int x = half + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = half + blockIdx.y;
+    if (x >= g.w1 - half) return;
+    uint32_t c[3] = {kTopNone, kTopNone, kTopNone};
+    int dd[3] = {0, 0, 0};
+    if (!black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+        const float *o = g.out + (size_t)y * g.out_pitch + x;
+        const int d = (int)o[0];
+        if (left_candidate_ok(g, x, d, half)) { // otherwise: no candidate at all, the value x stays
+            dd[0] = d;
+            c[0] = left_cost_int(g, x, y, d, half);
+            // Two more TRUE candidates with their true costs: what the upper and the left neighbour
+            // hold now.  Listing more candidates never changes the minimum; when a neighbour keeps
+            // its value (most do) the raster pass finds its cost here instead of summing a window.
+            int n = 1;
+            const float nb[2] = {y >= 1 ? o[-(ptrdiff_t)g.out_pitch] : 0.0f, x >= 1 ? o[-1] : 0.0f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = (int)nb[k];
+                if ((float)e == nb[k] && e != d && (n == 1 || e != dd[1]) && left_candidate_ok(g, x, e, half)) {
+                    dd[n] = e;
+                    c[n] = left_cost_int(g, x, y, e, half);
+                    ++n;
+                }
+            }
+        }
+    }
+    uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
+    reinterpret_cast<uint2 *>(t)[0] = make_uint2(c[0], (uint32_t)dd[0]);
+    reinterpret_cast<uint2 *>(t)[1] = make_uint2(c[1], (uint32_t)dd[1]);
+    reinterpret_cast<uint2 *>(t)[2] = make_uint2(c[2], (uint32_t)dd[2]);
+}
+
+constexpr int kWaveRows = 1024; // rows per band = threads of the one workgroup
+
+// Sliding window sums.  The cost of (x, y, d) follows from the cost of (x-1, y, d) -- one window
+// column enters, one leaves -- or from the cost of (x, y-1, d) -- one window row enters, one leaves.
+// The raster pass is ONE workgroup whose step time is the latency of these sums, so on the planes
+// the loads of both lines are issued in batches of 8 pixels (clamped index, the tail masked) rather
+// than one dependent load after the other.
+template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
+__device__ __forceinline__ uint32_t left_two_lines(uint32_t c_prev, const uint32_t *a_in, const uint32_t *b_in,
+                                                   const uint32_t *a_out, const uint32_t *b_out, int n, int sa, int sb)
+{
+    uint32_t in = 0, out = 0;
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        uint32_t ai[8], bi[8], ao[8], bo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = min(r0 + k, n - 1);
+            ai[k] = a_in[r * sa]; bi[k] = b_in[r * sb];
+            ao[k] = a_out[r * sa]; bo[k] = b_out[r * sb];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (r0 + k < n) {
+                if constexpr (MODE == 0) {
+                    in = pix_sad(ai[k], bi[k], in);
+                    out = pix_sad(ao[k], bo[k], out);
+                } else { // (a-b)^2 = a^2 + b^2 - 2ab per pixel, exact in 32 bits
+                    in += pix_dot<MODE == 2>(ai[k], ai[k], 0u) + pix_dot<MODE == 2>(bi[k], bi[k], 0u) - 2u * pix_dot<MODE == 2>(ai[k], bi[k], 0u);
+                    out += pix_dot<MODE == 2>(ao[k], ao[k], 0u) + pix_dot<MODE == 2>(bo[k], bo[k], 0u) - 2u * pix_dot<MODE == 2>(ao[k], bo[k], 0u);
+                }
+            }
+        }
+    }
+    return c_prev + in - out;
+}
+
+__device__ __forceinline__ uint32_t left_two_lines(const SmoothLeftArgs &g, uint32_t c_prev, const uint32_t *a_in, const uint32_t *b_in,
+                                                   const uint32_t *a_out, const uint32_t *b_out, int sa, int sb)
+{
+    if (!g.ssd) return left_two_lines<0>(c_prev, a_in, b_in, a_out, b_out, g.block_size, sa, sb);
+    return g.centred ? left_two_lines<2>(c_prev, a_in, b_in, a_out, b_out, g.block_size, sa, sb)
+                     : left_two_lines<1>(c_prev, a_in, b_in, a_out, b_out, g.block_size, sa, sb);
+}
+
+// cost of (x, y, d) from the cost of (x - 1, y, d)
+__device__ __forceinline__ uint32_t left_slide(const SmoothLeftArgs &g, uint32_t c_prev, int x, int y, int d, int half)
+{
+    if (g.A) {
+        const uint32_t *pa = g.A + (size_t)(y - half) * g.pitch_a + g.pad_a;
+        const uint32_t *pb = g.B + (size_t)(y - half) * g.pitch_b + (g.pad_b - d);
+        return left_two_lines(g, c_prev, pa + (x + half), pb + (x + half), pa + (x - 1 - half), pb + (x - 1 - half), g.pitch_a, g.pitch_b);
+    }
+    return c_prev + left_col_cost(g, x + half, y, d, half) - left_col_cost(g, x - 1 - half, y, d, half);
+}
+
+// cost of (x, y, d) from the cost of (x, y - 1, d)
+__device__ __forceinline__ uint32_t left_slide_down(const SmoothLeftArgs &g, uint32_t c_above, int x, int y, int d, int half)
+{
+    if (g.A) {
+        const uint32_t *pa = g.A + (x - half + g.pad_a), *pb = g.B + (x - half - d + g.pad_b);
+        return left_two_lines(g, c_above, pa + (size_t)(y + half) * g.pitch_a, pb + (size_t)(y + half) * g.pitch_b,
+                              pa + (size_t)(y - 1 - half) * g.pitch_a, pb + (size_t)(y - 1 - half) * g.pitch_b, 1, 1);
+    }
+    const uint8_t *l0 = g.L + 3 * (x - half), *r0 = g.R + 3 * (x - d - half);
+    return c_above + window_cost(l0 + (size_t)(y + half) * g.s1, g.s1, r0 + (size_t)(y + half) * g.s2, g.s2, g.block_size, 1, g.ssd) -
+           window_cost(l0 + (size_t)(y - 1 - half) * g.s1, g.s1, r0 + (size_t)(y - 1 - half) * g.s2, g.s2, g.block_size, 1, g.ssd);
+}
+
+__global__ void __launch_bounds__(kWaveRows) ws_smooth_left_wave_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
+                                                                        int top_pitch)
+{
+    __shared__ float vbuf[2][kWaveRows + 1];    // [step parity][row + 1]: the value a row produced in that step
+    __shared__ uint32_t cbuf[2][kWaveRows + 1]; // ... and that value's window cost there (kTopNone: not known)
+    const int t = threadIdx.x;
     const int half = (g.block_size - 1) / 2;
     const int height = min(g.h1, g.h2);
-    const bool other_can_win = !(g.s >= 1.0);
-    for (int x = tid; x < g.w1; x += nt) prev[x] = 0.0f;
-    if (half > 0)
-        for (int x = tid; x < g.w1; x += nt) prev[x] = g.out[(size_t)(half - 1) * g.out_pitch + x];
-    __syncthreads();
-    for (int y = half; y < height - half; ++y) {
+    const int iw = g.w1 - 2 * half, ih = height - 2 * half; // interior
+    const bool other_can_win = !(g.s >= 1.0); // (see above: for s >= 1 an unlisted neighbour value never wins)
+    const bool slide_ok = g.block_size > 2;   // (a 1-pixel window is cheaper summed than slid)
+    for (int band = 0; band * kWaveRows < ih; ++band) {
+        const int y = half + band * kWaveRows + t;
+        const bool row_ok = y < height - half;
+        const int nrows = min(kWaveRows, ih - band * kWaveRows);
+        const int nsteps = iw + nrows - 1;
         float *orow = g.out + (size_t)y * g.out_pitch;
-        int td[kSmoothLeftGenPer][3], du[kSmoothLeftGenPer], lastl[kSmoothLeftGenPer];
-        double tm[kSmoothLeftGenPer][3], uu[kSmoothLeftGenPer], ul[kSmoothLeftGenPer];
-        bool act[kSmoothLeftGenPer];
-#pragma unroll
-        for (int k = 0; k < kSmoothLeftGenPer; ++k) {
-            const int x = tid + k * nt;
-            act[k] = false;
-            du[k] = 0; lastl[k] = -1; uu[k] = ul[k] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { td[k][i] = 0; tm[k][i] = 0.0; }
-            if (x < g.w1) {
-                cur[x] = orow[x]; // border zeros, black zeros and "no candidate" values stay as the search left them
-                if (x >= half && x < g.w1 - half && !black3(g.L + (size_t)y * g.s1 + 3 * x)) {
-                    const uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
-                    const int up = (int)prev[x];
-                    const bool up_ok = y >= 1 && (float)up == prev[x] && left_candidate_ok(g, x, up, half);
-                    bool up_listed = false;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const uint2 e = reinterpret_cast<const uint2 *>(t)[i];
-                        if (e.x == kTopNone) continue;
-                        act[k] = true;
-                        td[k][i] = (int)e.y;
-                        double m = g.ssd ? sqrt((double)e.x) : (double)e.x;
-                        if (up_ok && up == (int)e.y) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
-                        tm[k][i] = m;
-                    }
-                    if (act[k] && up_ok && !up_listed) {
-                        du[k] = up;
-                        uu[k] = left_dist(g, x, y, up, half) * g.s;
-                    }
-                    if (act[k]) { // the guess without a left neighbour
-                        LeftBest b{1.7976931348623157e308, -1};
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            if (td[k][i] > 0) b.consider(tm[k][i], td[k][i]);
-                        if (du[k] > 0) b.consider(uu[k], du[k]);
-                        cur[x] = b.d >= 0 ? (float)b.d : (float)x;
-                    }
-                }
-            }
+        const float *urow = g.out + (size_t)(y - 1) * g.out_pitch; // read by row 0 of the band only
+        const uint32_t *trow = top + (size_t)y * top_pitch * 6;
+        // the thread's running state along its row
+        float lv = 0.0f;          // value of (y, x-1); the ring column left of the interior holds 0
+        uint32_t lcost = 0;       // window cost of (x-1, lv) ...
+        bool lknown = false;      // ... if it is known
+        int uv = 0, ux = -2;      // last upper-neighbour value whose cost was needed, at column ux
+        uint32_t ucost = 0;
+        // entry of the pixel this thread handles next (prefetched one step ahead)
+        uint2 e0 = make_uint2(kTopNone, 0u), e1 = e0, e2 = e0;
+        float up0 = 0.0f;
+        if (row_ok && t == 0) {
+            const uint32_t *q = trow + (size_t)half * 6;
+            e0 = reinterpret_cast<const uint2 *>(q)[0]; e1 = reinterpret_cast<const uint2 *>(q)[1]; e2 = reinterpret_cast<const uint2 *>(q)[2];
+            if (y >= 1) up0 = urow[half];
         }
-        if (tid < 3) changed[tid] = 0;
-        __syncthreads();
-        // one barrier per iteration: guesses are double-buffered and the "changed" flag rotates over
-        // three slots (slot it+2 is cleared while slot it is read and slot it+1 may already be set)
-        for (int it = 0; it < g.w1 + 1; ++it) {
-            const int slot = it % 3;
-#pragma unroll
-            for (int k = 0; k < kSmoothLeftGenPer; ++k) {
-                const int x = tid + k * nt;
-                if (x >= g.w1) continue;
-                float res = cur[x];
-                if (act[k]) {
-                    const float lf = x >= 1 ? cur[x - 1] : 0.0f;
-                    const int l = (int)lf;
-                    const bool l_ok = x >= 1 && (float)l == lf && left_candidate_ok(g, x, l, half);
+        for (int k = 0; k < nsteps; ++k) {
+            const int xs = k - t;
+            const bool in = row_ok && xs >= 0 && xs < iw;
+            const int x = half + xs;
+            // prefetch the next pixel's entry (and, for the band's first row, its upper neighbour)
+            uint2 n0 = make_uint2(kTopNone, 0u), n1 = n0, n2 = n0;
+            float nup0 = 0.0f;
+            if (row_ok && xs + 1 >= 0 && xs + 1 < iw) {
+                const uint32_t *q = trow + (size_t)(x + 1) * 6;
+                n0 = reinterpret_cast<const uint2 *>(q)[0]; n1 = reinterpret_cast<const uint2 *>(q)[1]; n2 = reinterpret_cast<const uint2 *>(q)[2];
+                if (t == 0 && y >= 1) nup0 = urow[x + 1];
+            }
+            if (in) {
+                const float upf = t == 0 ? up0 : vbuf[(k + 1) & 1][t];
+                const uint32_t c_above = t == 0 ? kTopNone : cbuf[(k + 1) & 1][t]; // cost of (x, y-1, up)
+                float v;
+                if (e0.x == kTopNone) {
+                    v = orow[x]; // black (0) or no candidate at all (x): fixed
+                    lknown = false;
+                } else {
+                    const int up = (int)upf;
+                    const bool up_ok = y >= 1 && (float)up == upf && left_candidate_ok(g, x, up, half);
+                    const int l = (int)lv;
+                    const bool l_ok = x >= 1 && (float)l == lv && left_candidate_ok(g, x, l, half);
                     LeftBest b{1.7976931348623157e308, -1};
-                    bool l_listed = false;
+                    uint32_t bcost = 0; // integer window cost of the running winner
+                    bool up_listed = false, l_listed = false;
+                    const uint2 es[3] = {e0, e1, e2};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        if (td[k][i] <= 0) continue;
-                        double m = tm[k][i];
-                        if (l_ok && l == td[k][i]) { m *= g.s; l_listed = true; } // the left factor second (:71-73)
-                        b.consider(m, td[k][i]);
+                        if (es[i].x == kTopNone) continue;
+                        const int d = (int)es[i].y;
+                        double m = left_dist_of(g, es[i].x);
+                        if (up_ok && up == d) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
+                        if (l_ok && l == d) { m *= g.s; l_listed = true; }    // the left factor second (:71-73)
+                        const int before = b.d;
+                        b.consider(m, d);
+                        if (b.d != before) bcost = es[i].x;
                     }
-                    if (du[k] > 0) {
-                        double m = uu[k];
-                        if (l_ok && l == du[k]) { m *= g.s; l_listed = true; }
-                        b.consider(m, du[k]);
+                    // the listed candidates' costs also serve the sliding sums below
+                    uint32_t cu = 0;
+                    bool cu_known = false;
+                    if (up_ok && !up_listed && other_can_win) {
+                        if (slide_ok && c_above != kTopNone) cu = left_slide_down(g, c_above, x, y, up, half);
+                        else if (slide_ok && ux == x - 1 && uv == up) cu = left_slide(g, ucost, x, y, up, half);
+                        else if (slide_ok && lknown && l == up && l_ok) cu = left_slide(g, lcost, x, y, up, half);
+                        else cu = left_cost_int(g, x, y, up, half);
+                        cu_known = true;
+                        double m = left_dist_of(g, cu) * g.s;
+                        if (l_ok && l == up) { m *= g.s; l_listed = true; }
+                        const int before = b.d;
+                        b.consider(m, up);
+                        if (b.d != before) bcost = cu;
+                    } else if (up_ok && !up_listed && l_ok && l == up) {
+                        l_listed = true; // (s >= 1: neither can win)
                     }
-                    // (for s >= 1 an unlisted left value cannot win: two of t0..t2 are untouched, rank
-                    // before it, and its own distance only grows -- so its window is never summed)
                     if (l_ok && !l_listed && other_can_win) {
-                        if (lastl[k] != l) {
-                            ul[k] = left_dist(g, x, y, l, half);
-                            lastl[k] = l;
-                        }
-                        b.consider(ul[k] * g.s, l);
+                        const uint32_t cl = slide_ok && lknown ? left_slide(g, lcost, x, y, l, half) : left_cost_int(g, x, y, l, half);
+                        const int before = b.d;
+                        b.consider(left_dist_of(g, cl) * g.s, l);
+                        if (b.d != before) bcost = cl;
                     }
-                    res = b.d >= 0 ? (float)b.d : (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
+                    // remember the upper value's cost for the next column
+                    if (up_ok) {
+                        if (cu_known) { uv = up; ucost = cu; ux = x; }
+                        else if (up_listed) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i)
+                                if (es[i].x != kTopNone && (int)es[i].y == up) { uv = up; ucost = es[i].x; ux = x; }
+                        }
+                    }
+                    if (b.d >= 0) {
+                        v = (float)b.d;
+                        lcost = bcost;
+                        lknown = true;
+                    } else {
+                        v = (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
+                        lknown = false;
+                    }
                 }
-                nxt[x] = res;
-                if (res != cur[x]) changed[slot] = 1;
+                orow[x] = v;
+                lv = v;
+                vbuf[k & 1][t + 1] = v;
+                cbuf[k & 1][t + 1] = lknown ? lcost : kTopNone;
             }
+            e0 = n0; e1 = n1; e2 = n2; up0 = nup0;
             __syncthreads();
-            float *t = cur; cur = nxt; nxt = t;
-            const int any = changed[slot];
-            if (tid == 0) changed[(it + 2) % 3] = 0;
-            if (!any) break;
         }
-        for (int x = tid; x < g.w1; x += nt) orow[x] = cur[x];
+        __threadfence(); // the next band's first row reads this band's last row from the map
         __syncthreads();
-        { float *t = prev; prev = cur; cur = t; }
     }
 }
 
@@ -822,23 +819,15 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     a.L = g.L; a.R = g.R; a.w1 = g.w1; a.h1 = g.h1; a.s1 = g.s1; a.w2 = g.w2; a.h2 = g.h2; a.s2 = g.s2;
     a.block_size = g.block_size; a.max_d = g.max_d; a.ssd = g.ssd; a.s = s;
     a.out = g.out; a.out_pitch = g.out_pitch;
-    if (g.w1 > kSmoothLeftPer * 1024) return hipErrorInvalidValue;
-    if (s >= 0.0 && s <= 1.0) {
-        const size_t lds = (size_t)g.w1 * 20; // 3 float rows + 2 rows of integer costs
-        if (lds > 48 * 1024) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(ws_smooth_left_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (err != hipSuccess) return err;
-        }
-        hipLaunchKernelGGL(ws_smooth_left_kernel, dim3(1), dim3(1024), lds, st, a);
-        return hipGetLastError();
-    }
-    if (!top3 || g.w1 > kSmoothLeftGenPer * 1024) return hipErrorInvalidValue;
+    if (!top3) return hipErrorInvalidValue;
     const int half = (g.block_size - 1) / 2;
     const int iw = g.w1 - 2 * half, ih = std::min(g.h1, g.h2) - 2 * half;
     if (iw <= 0 || ih <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
-    hipLaunchKernelGGL(ws_smooth_left_general_kernel, dim3(1), dim3(1024), (size_t)3 * g.w1 * sizeof(float), st, a, top3, g.w1);
+    if (s >= 0.0 && s <= 1.0)
+        hipLaunchKernelGGL(ws_left_cost_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
+    else
+        hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
+    hipLaunchKernelGGL(ws_smooth_left_wave_kernel, dim3(1), dim3(kWaveRows), 0, st, a, top3, g.w1);
     return hipGetLastError();
 }
 

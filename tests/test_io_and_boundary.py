@@ -55,7 +55,7 @@ def test_validate_mirrors_the_reference_exceptions(wslib):
     assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 7, -1, 64), (100, 200), (100, 200)) == -2
     assert ws.validate(ws.make_params(ws.VIEW_LEFT, 7, 0, 64, smooth_factor=0.9), (100, 200), (100, 200)) == 0
     assert ws.validate(ws.make_params(ws.VIEW_LEFT, 7, 0, 64, smooth_factor=1.2), (100, 200), (100, 200)) == 0
-    assert ws.validate(ws.make_params(ws.VIEW_LEFT, 7, 0, 64, smooth_factor=0.9), (100, 5000), (100, 5000)) == -3   # raster pass: <= 4096 columns
+    assert ws.validate(ws.make_params(ws.VIEW_LEFT, 7, 0, 64, smooth_factor=0.9), (100, 5000), (100, 5000)) == 0
     assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 17, 0, 200, smooth_factor=0.9), (100, 200), (100, 200)) == 0
     assert ws.validate(ws.make_params(ws.VIEW_LINEAR, 1, 0, 200, smooth_factor=0.9), (100, 200), (100, 200)) == 0
     assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 7, 0, 64, var_block=True), (100, 200), (100, 200)) == 0

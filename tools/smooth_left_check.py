@@ -12,7 +12,7 @@ def cmp(name, got, ref):
     bad = np.argwhere(got != ref)
     print(("ok  " if len(bad) == 0 else "FAIL"), name, len(bad), bad[:4].tolist(), [(got[tuple(b)], ref[tuple(b)]) for b in bad[:4]], flush=True)
     ok &= len(bad) == 0
-for levels, (w, h) in [(256, (300, 60)), (3, (260, 50)), (2, (500, 30)), (4, (1100, 24)), (256, (97, 41))]:
+for levels, (w, h) in [(256, (300, 60)), (3, (260, 50)), (2, (500, 30)), (4, (1100, 24)), (256, (97, 41)), (256, (60, 1300)), (3, (4200, 20))]:
     if levels == 256:
         L, R, _ = make_pair(w, h, 48, seed=w)
     else:
