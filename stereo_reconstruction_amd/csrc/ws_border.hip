@@ -210,6 +210,60 @@ hipError_t launch_generic(const GenericArgs &g, hipStream_t s)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// LinearSearch (LinearSearch.cpp:10-59): single pixels, no window.  A workgroup takes 256
+// consecutive columns of one row, packs the left row's segment [x0, x0 + 256 + range) into LDS
+// once (pixel dword + its sum of squares), and every thread sweeps its candidates from there:
+// (a-b)^2 summed over the channels = a.a + b.b - 2 a.b, one v_dot4 per candidate.
+// ------------------------------------------------------------------------------------------
+constexpr int kLinearMaxRange = 4096;
+
+__global__ void __launch_bounds__(256) ws_linear_kernel(const GenericArgs g)
+{
+    extern __shared__ uint32_t lin_lds[]; // [n] pixels, [n] sums of squares
+    const int y = blockIdx.y, x0 = blockIdx.x * 256, tid = threadIdx.x;
+    const int n = 256 + g.linear_range;
+    uint32_t *lp = lin_lds, *lq = lin_lds + n;
+    if (y < g.h1) {
+        const uint8_t *lrow = g.L + (size_t)y * g.s1;
+        for (int i = tid; i < n; i += 256) {
+            const int k = x0 + i;
+            uint32_t v = 0;
+            if (k < g.w1) v = (uint32_t)lrow[3 * k] | ((uint32_t)lrow[3 * k + 1] << 8) | ((uint32_t)lrow[3 * k + 2] << 16);
+            lp[i] = v;
+            lq[i] = pix_dot<false>(v, v, 0u);
+        }
+    }
+    __syncthreads();
+    const int x = x0 + tid;
+    if (x >= g.w2) return;
+    float val = 0.0f;
+    // the black test reads the LEFT pixel (LinearSearch.cpp:24), where there is one
+    if (y < g.h1 && !(x < g.w1 && lp[tid] == 0u)) {
+        const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
+        const uint32_t a = (uint32_t)pr[0] | ((uint32_t)pr[1] << 8) | ((uint32_t)pr[2] << 16);
+        const uint32_t aa = pix_dot<false>(a, a, 0u);
+        uint32_t best = 0xffffffffu;
+        int bd = -x; // no candidate: col stays 0 (LinearSearch.cpp:33,53)
+        const int d_end = min(g.linear_range, g.w1 - x); // candidates beyond the row's end are skipped, not read
+#pragma unroll 4
+        for (int d = g.min_d; d < d_end; ++d) {
+            const uint32_t c = aa + lq[tid + d] - 2u * pix_dot<false>(a, lp[tid + d], 0u);
+            if (c < best) { best = c; bd = d; } // strict: ties go to the smaller d
+        }
+        val = (float)bd;
+    }
+    g.out[(size_t)y * g.out_pitch + x] = val;
+}
+
+hipError_t launch_linear(const GenericArgs &g, hipStream_t s)
+{
+    if (g.linear_range > kLinearMaxRange) return launch_generic(g, s);
+    dim3 grid(ceil_div(g.w2, 256), g.h2);
+    hipLaunchKernelGGL(ws_linear_kernel, grid, dim3(256), (size_t)(256 + g.linear_range) * 8, s, g);
+    return hipGetLastError();
+}
+
 // Sub-pixel refinement (build extension): the integer map is already final; a
 // pixel is refined when d-1, d and d+1 are all candidates the search itself would have tried.
 __global__ void __launch_bounds__(256) ws_refine_kernel(const GenericArgs g)

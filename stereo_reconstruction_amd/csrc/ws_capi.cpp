@@ -318,7 +318,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ctx->last_wgs = m.tiles * m.strips;
         ctx->last_lds = (int)m.lds_bytes;
     } else {
-        ctx->last_kernel = "ws_generic_kernel";
+        ctx->last_kernel = p->view == WS_VIEW_LINEAR ? "ws_linear_kernel" : "ws_generic_kernel";
         ctx->last_threads = 256;
         ctx->last_wgs = ((ow + 255) / 256) * (p->view == WS_VIEW_LEFT ? L->height : R->height);
         ctx->last_lds = 0;
@@ -326,6 +326,8 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     // everything the marching kernel does not own: border ring, rows past min(h1,h2), or all of it
     if (march && p->view == WS_VIEW_RIGHT)
         WS_HIP(ctx, launch_ring(c, ring_a, ring_b, ga, out, out_stride, ctx->last_cost, c.wa, s));
+    else if (!march && p->view == WS_VIEW_LINEAR)
+        WS_HIP(ctx, launch_linear(ga, s));
     else if (!march)
         WS_HIP(ctx, launch_generic(ga, s));
     ctx->last_march = march;

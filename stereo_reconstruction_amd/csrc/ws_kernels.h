@@ -85,6 +85,8 @@ struct GenericArgs {
     int bs_pitch;
 };
 hipError_t launch_generic(const GenericArgs &g, hipStream_t s);
+// LinearSearch through LDS (falls back to launch_generic for ranges beyond 4096 candidates)
+hipError_t launch_linear(const GenericArgs &g, hipStream_t s);
 // Right-view border ring on the packed (mirrored) planes: sliding sums along runs, lanes over d.
 hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip, float *out, int out_pitch,
                        int32_t *cost_out, int cost_pitch, hipStream_t s);

@@ -116,6 +116,22 @@ def test_linear_search(wslib, gpu_ctx, oracle):
     assert np.array_equal(got, oracle.linear(left, right))
 
 
+@pytest.mark.parametrize("shape", [(300, 40, 280, 40), (280, 40, 300, 40), (600, 30, 600, 36), (50, 20, 50, 20)])
+@pytest.mark.parametrize("search_range", [1, 7, 200, 700, 5000])
+def test_linear_search_shapes_and_ranges(wslib, gpu_ctx, oracle, shape, search_range):
+    """Left narrower / wider / shorter than right, ranges beyond the row and beyond the LDS kernel's
+    4096 candidates (brute-force fallback), black left pixels, few grey levels (ties -> smallest d)."""
+    w1, h1, w2, h2 = shape
+    rng = np.random.default_rng(w1 + search_range)
+    left = (rng.integers(0, 4, size=(h1, w1, 3)) * 85).astype(np.uint8)
+    right = (rng.integers(0, 4, size=(h2, w2, 3)) * 85).astype(np.uint8)
+    left[3:6, 10:30] = 0
+    got = wslib.LinearSearch(left, right, context=gpu_ctx, search_range=search_range).computeDisparityMap(1.0)
+    assert np.array_equal(got, oracle.linear(left, right, search_range=search_range))
+    got = wslib.LinearSearch(left, right, context=gpu_ctx, search_range=search_range).computeDisparityMap(0.5)
+    assert np.array_equal(got, oracle.linear(left, right, smooth=0.5, search_range=search_range))
+
+
 @pytest.mark.parametrize("view", ["left", "right"])
 @pytest.mark.parametrize("cost", ["ssd", "sad"])
 def test_subpixel_within_tolerance(wslib, gpu_ctx, oracle, view, cost):
