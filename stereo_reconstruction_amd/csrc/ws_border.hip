@@ -400,9 +400,11 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s)
 
 // ------------------------------------------------------------------------------------------
 // varBlock (BlockSearch.cpp:125-145, right view): while the window's centred norm is below
-// `thres` the block grows by 4; then the search runs with that pixel's own window.  Windows differ
-// from pixel to pixel, so no sliding sums: one wavefront per pixel, lanes share the window pixels
-// for the texture test and split the disparities for the search; wave-wide sums / min by shuffles.
+// `thres` the block grows by 4; then the search runs with that pixel's own window.  One wavefront
+// per pixel: the lanes share the window pixels for the texture test; where the window grew (no
+// sliding sums: it differs from pixel to pixel) they split the disparities for the search, wave-wide
+// sums / min by shuffles.  Pixels whose window did not grow keep the ordinary search's result,
+// which is in the map already.
 // cv::mean / cv::subtract / cv::norm semantics (OpenCV 4.x restated; the library is
 // un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even(p - mean)), L2 norm.
 // Growth stops when the window no longer changes (the reference would loop forever there).
@@ -451,6 +453,12 @@ __global__ void __launch_bounds__(256) ws_varblock_kernel(const GenericArgs g, d
             const int l2 = min(x, hb), r2 = min(g.w2 - x - 1, hb), u2 = min(y, hb), d2 = min(g.h2 - y - 1, hb);
             if (l2 == left && r2 == right && u2 == up && d2 == down) break; // cannot grow any more
             left = l2; right = r2; up = u2; down = d2;
+        }
+        // A window that did not grow is the ordinary right-view window: the marching / ring kernels
+        // have searched it already (launch order in ws_capi.cpp), only the block size is recorded.
+        if (bs == g.block_size) {
+            if (lane == 0) bs_plane[(size_t)y * bs_pitch + x] = (int16_t)bs;
+            return;
         }
         // the search with this pixel's window: lanes over d, d ascending inside a lane
         const int ww = left + right, wh = up + down;

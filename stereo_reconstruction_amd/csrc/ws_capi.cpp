@@ -256,9 +256,14 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ctx->last_cost = nullptr;
     if (p->view == WS_VIEW_RIGHT) ctx->var_block_ran = false;
     if (p->view == WS_VIEW_RIGHT && p->var_block) {
-        // per-pixel windows: no sliding sums, one wave per pixel (ws_varblock_kernel)
+        // the ordinary search first; then one wave per pixel decides the window (ws_varblock_kernel)
+        // and searches again only where it grew
+        ws_params q = *p;
+        q.var_block = 0;
+        q.subpixel = 0;
+        int rc = run_search(ctx, &q, L, R, out, out_stride, s);
+        if (rc != WS_OK) return rc;
         const int bs_pitch = (R->width + 63) & ~63;
-        int rc;
         if ((rc = ensure(ctx, ctx->bs_plane, (size_t)bs_pitch * R->height * 2)) != WS_OK) return rc;
         if ((rc = ensure(ctx, ctx->max_block, 64)) != WS_OK) return rc;
         WS_HIP(ctx, launch_varblock(ga, p->thres, static_cast<int16_t *>(ctx->bs_plane.p), bs_pitch,
