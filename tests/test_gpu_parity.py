@@ -286,8 +286,14 @@ def test_randomised_differential(wslib, gpu_ctx, oracle, seed):
         got = b.computeDisparityMapLeft(smooth)
         want = oracle.block_left(left, right, bs, mind, maxd, smooth=smooth, cost=cost, threads=8)
     else:
-        got = b.computeDisparityMapRight(smooth)
-        want = oracle.block_right(left, right, bs, mind, maxd, smooth=smooth, cost=cost, threads=8)
+        var_block = bool(rng.random() < 0.25)
+        thres = float(rng.choice([10.0, 40.0, 150.0]))
+        got = b.computeDisparityMapRight(smooth, var_block, thres)
+        want = oracle.block_right(left, right, bs, mind, maxd, smooth=smooth, var_block=var_block, thres=thres,
+                                  cost=cost, threads=8, return_max_block=var_block)
+        if var_block:
+            want, want_mb = want
+            assert gpu_ctx.last_max_block(bs) == want_mb
     assert np.array_equal(got, want), (view, bs, mind, maxd, cost, smooth, left.shape, right.shape, levels)
 
 
