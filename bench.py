@@ -92,6 +92,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # the extension normally travels with the tree; a tree without it gets it built once per node
+    from stereo_reconstruction_amd import build as ws_build
+    if not os.path.exists(os.environ.get("WS_STEREO_LIB", ws_build.LIB)):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            ws_build.build()
+        if dist is not None:
+            dist.barrier()
     dev = torch.device("cuda", local_rank)
     ctx = ws.WindowSearch(local_rank)
     stream = torch.cuda.current_stream().cuda_stream

@@ -37,11 +37,17 @@ def build(force=False, verbose=False):
         return LIB
     # -ffp-contract=off: the few floating-point kernels (warp, depth, back-projection, smoothFactor)
     # must round every product like the reference's x86-64 build does; the hot kernels are integer
+    tmp = LIB + ".tmp.%d" % os.getpid()  # written aside and renamed: a concurrent loader never sees half a file
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
