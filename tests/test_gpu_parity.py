@@ -376,6 +376,25 @@ def test_two_contexts_from_two_threads(wslib, oracle):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 1), (1, 4), (5, 5), (9, 3), (16, 16), (17, 2)])
+def test_tiny_images_every_path(wslib, gpu_ctx, oracle, shape):
+    """Images smaller than the window: no interior, everything is border / fallback, in every path."""
+    w, h = shape
+    rng = np.random.default_rng(w * 31 + h)
+    left = rng.integers(0, 3, size=(h, w, 3)).astype(np.uint8) * 100
+    right = rng.integers(0, 3, size=(h, w, 3)).astype(np.uint8) * 100
+    for bs in (1, 3, 7):
+        for s in (1.0, 0.9, 1.5):
+            b = wslib.BlockSearch(left, right, bs, 0, 6, context=gpu_ctx)
+            assert np.array_equal(b.computeDisparityMapLeft(s), oracle.block_left(left, right, bs, 0, 6, smooth=s)), (bs, s)
+            assert np.array_equal(b.computeDisparityMapRight(s), oracle.block_right(left, right, bs, 0, 6, smooth=s)), (bs, s)
+        got = wslib.BlockSearch(left, right, bs, 0, 6, context=gpu_ctx).computeDisparityMapRight(0.9, True, 150.0)
+        assert np.array_equal(got, oracle.block_right(left, right, bs, 0, 6, smooth=0.9, var_block=True, thres=150.0)), bs
+    for s in (1.0, 0.5):
+        got = wslib.LinearSearch(left, right, context=gpu_ctx, search_range=5).computeDisparityMap(s)
+        assert np.array_equal(got, oracle.linear(left, right, smooth=s, search_range=5))
+
+
 def test_errors_are_reported_not_computed(wslib, gpu_ctx):
     left, right, _ = make_pair(100, 40, 16, seed=1)
     with pytest.raises(wslib.WsError) as e:
