@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int n_hr
         }
     }
     __syncthreads();
-    if (threadIdx.x < n) {
+    if ((int)threadIdx.x < n) {
         const int i = threadIdx.x;
         const int x = horizontal ? x0 + i : x0, y = horizontal ? y0 : y0 + i;
         const uint32_t black = MODE == 2 ? kCentre : 0u;
