@@ -137,9 +137,10 @@ int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_d
                      const ws_image *right_dev, float *out_dev, int out_stride, void *stream);
 
 /*
- * Batched host form for many independent pairs (BASELINE.json config 4): enqueue copies +
- * kernels for one pair on the context's stream with pinned staging, return at once;
- * ws_wait() blocks until every enqueued pair's map has landed in its `out`.
+ * Batched host form for many independent pairs (BASELINE.json config 4): two pairs are kept in
+ * flight -- while one is searched, the next one's images go up and the previous one's map comes
+ * down on a second stream.  The images and `out` must stay valid and untouched until ws_wait(),
+ * which blocks until every enqueued pair's map has landed in its `out`.
  */
 int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left,
                     const ws_image *right, void *out, int out_stride, int out_dtype);

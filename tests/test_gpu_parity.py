@@ -312,6 +312,23 @@ def test_strided_buffers_and_extreme_arguments(wslib, gpu_ctx, oracle):
     out = np.full((50, 256), -5.0, dtype=np.float64)                 # out_stride 256 > width 220
     rc = lib.ws_search_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), out.ctypes.data, 256, 1)
     assert rc == 0 and np.array_equal(out[:, :220], want) and (out[:, 220:] == -5.0).all()
+    # the batched entry point with the same strided buffers, three pairs in flight, then a wide ROI
+    # (stride > 2 x row: copied row by row) and a row length that is not a multiple of 4 bytes
+    outs = [np.full((50, 256), -5.0, dtype=np.float64) for _ in range(3)]
+    for o in outs:
+        assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), o.ctypes.data, 256, 1) == 0
+    assert lib.ws_wait(gpu_ctx._h) == 0
+    for o in outs:
+        assert np.array_equal(o[:, :220], want) and (o[:, 220:] == -5.0).all()
+    nl, nr = big_l[5:55, 10:81], big_r[5:55, 10:81]                 # 71 columns: 213 bytes per row, stride 780
+    nwant = oracle.block_left(np.ascontiguousarray(nl), np.ascontiguousarray(nr), 7, 0, 40)
+    NLi = wslib._Image(nl.ctypes.data, 71, 50, nl.strides[0])
+    NRi = wslib._Image(nr.ctypes.data, 71, 50, nr.strides[0])
+    o1, o2 = np.zeros((50, 71), dtype=np.float32), np.zeros((50, 71), dtype=np.float32)
+    assert lib.ws_search_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(NLi), ctypes.byref(NRi), o1.ctypes.data, 71, 0) == 0
+    assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(NLi), ctypes.byref(NRi), o2.ctypes.data, 71, 0) == 0
+    assert lib.ws_wait(gpu_ctx._h) == 0
+    assert np.array_equal(o1.astype(np.float64), nwant) and np.array_equal(o2.astype(np.float64), nwant)
     # the same through the device entry point with strided device tensors
     tl, tr = torch.from_numpy(big_l).cuda()[5:55, 10:230], torch.from_numpy(big_r).cuda()[5:55, 10:230]
     to = torch.full((50, 256), -5.0, dtype=torch.float32, device="cuda")
@@ -429,7 +446,7 @@ def test_device_resident_path_and_f32_output(wslib, gpu_ctx, oracle):
 
 
 def test_batched_host_path_equals_single_calls(wslib, gpu_ctx):
-    pairs = [make_pair(200 + 16 * i, 50 + i, 32, seed=40 + i)[:2] for i in range(4)]
+    pairs = [make_pair(201 + 17 * i, 50 + i, 32, seed=40 + i)[:2] for i in range(7)]   # odd widths, 7 > 2 slots
     p = wslib.make_params(wslib.VIEW_LEFT, 5, 0, 32, 1.0, "sad")
     many = gpu_ctx.search_many(p, pairs, dtype=np.float32)
     for (l, r), m in zip(pairs, many):
