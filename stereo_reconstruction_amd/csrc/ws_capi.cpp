@@ -97,6 +97,15 @@ int ensure(ws_context *ctx, DevBuf &b, size_t bytes)
     return WS_OK;
 }
 
+// rows of `width_bytes` between buffers with row pitches: one linear copy when both sides are dense
+// (the runtime's 2-D path is slow, very slow for row lengths that are not a multiple of 4 bytes)
+hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows,
+                     hipMemcpyKind kind, hipStream_t s)
+{
+    if (dpitch == width_bytes && spitch == width_bytes) return hipMemcpyAsync(dst, src, width_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
+}
+
 bool image_ok(const ws_image *im)
 {
     return im && im->data && im->width > 0 && im->height > 0 && im->stride >= 3 * im->width;
@@ -694,9 +703,9 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
     if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out64, n * 8)) != WS_OK) return rc;
     float *dmap = static_cast<float *>(ctx->d_out.p);
-    WS_HIP(ctx, hipMemcpy2DAsync(dmap, (size_t)width * 4, map, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
+    WS_HIP(ctx, copy_rows(dmap, (size_t)width * 4, map, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
     WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
-    WS_HIP(ctx, hipMemcpy2DAsync(map, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
+    WS_HIP(ctx, copy_rows(map, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
     WS_HIP(ctx, hipStreamSynchronize(s));
     return WS_OK;
 }
@@ -722,14 +731,24 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
     float *dpos = reinterpret_cast<float *>(base);           // n * 16 bytes, 16-byte aligned
     float *ddepth = reinterpret_cast<float *>(base + n * 16); // n * 4
     uint8_t *dcol = base + n * 20;                            // n * 4
-    WS_HIP(ctx, hipMemcpy2DAsync(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
-    if (positions)
-        WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, (size_t)width * 3, bgr->data, bgr->stride, (size_t)width * 3, height, hipMemcpyHostToDevice, s));
+    WS_HIP(ctx, copy_rows(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
+    int bgr_stride = width * 3;
+    if (positions) { // the colour image as one linear copy with its own row stride (see ws_search_host)
+        const bool lin = (size_t)bgr->stride <= (size_t)6 * width;
+        if (lin) {
+            bgr_stride = bgr->stride;
+            const size_t span = (size_t)bgr->stride * (height - 1) + (size_t)width * 3;
+            if ((rc = ensure(ctx, ctx->d_left, span)) != WS_OK) return rc;
+            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, bgr->data, span, hipMemcpyHostToDevice, s));
+        } else {
+            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, (size_t)width * 3, bgr->data, bgr->stride, (size_t)width * 3, height, hipMemcpyHostToDevice, s));
+        }
+    }
     WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
-                                      static_cast<const uint8_t *>(ctx->d_left.p), width * 3, depth ? ddepth : nullptr, width,
+                                      static_cast<const uint8_t *>(ctx->d_left.p), bgr_stride, depth ? ddepth : nullptr, width,
                                       positions ? dpos : nullptr, positions ? dcol : nullptr, input_is_depth, s));
     if (depth)
-        WS_HIP(ctx, hipMemcpy2DAsync(depth, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
+        WS_HIP(ctx, copy_rows(depth, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
     if (positions) {
         WS_HIP(ctx, hipMemcpyAsync(positions, dpos, n * 16, hipMemcpyDeviceToHost, s));
         WS_HIP(ctx, hipMemcpyAsync(colors, dcol, n * 4, hipMemcpyDeviceToHost, s));
