@@ -106,6 +106,15 @@ hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, s
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
 }
 
+// Is an image worth copying as one linear span, row padding included?  Yes unless it is a narrow
+// cut out of a much wider image AND big (the per-row path costs ~15 us per row).
+bool linear_span(const ws_image *im)
+{
+    const size_t dense = (size_t)im->width * 3 * im->height;
+    const size_t span = (size_t)im->stride * (im->height - 1) + (size_t)im->width * 3;
+    return span <= 2 * dense || span <= ((size_t)32 << 20);
+}
+
 bool image_ok(const ws_image *im)
 {
     return im && im->data && im->width > 0 && im->height > 0 && im->stride >= 3 * im->width;
@@ -508,9 +517,9 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     // One linear copy per image, row padding included (the kernels take any row stride): a 2-D copy
     // whose row length is not a multiple of 4 bytes -- 3 * width for most widths -- falls to a
     // per-row path in the runtime (measured: 15 ms instead of 0.2 ms for a 1482 x 994 image).
-    // Only an image cut out of a much wider one is copied row by row.
+    // Only a big image cut out of a much wider one is copied row by row (linear_span).
     const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
-    const bool lin_l = (size_t)left->stride <= 2 * lb, lin_r = (size_t)right->stride <= 2 * rb;
+    const bool lin_l = linear_span(left), lin_r = linear_span(right);
     const size_t span_l = lin_l ? (size_t)left->stride * (left->height - 1) + lb : lb * left->height;
     const size_t span_r = lin_r ? (size_t)right->stride * (right->height - 1) + rb : rb * right->height;
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
@@ -576,7 +585,7 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     Job &prev = ctx->jobs[ctx->job_next ^ 1];
     if ((rc = flush_job(ctx, job)) != WS_OK) return rc; // (only after an error left it pending)
     const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
-    const bool lin_l = (size_t)left->stride <= 2 * lb, lin_r = (size_t)right->stride <= 2 * rb;
+    const bool lin_l = linear_span(left), lin_r = linear_span(right);
     const size_t span_l = lin_l ? (size_t)left->stride * (left->height - 1) + lb : lb * left->height;
     const size_t span_r = lin_r ? (size_t)right->stride * (right->height - 1) + rb : rb * right->height;
     const size_t off_r = (span_l + 255) & ~(size_t)255;
@@ -734,7 +743,7 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
     WS_HIP(ctx, copy_rows(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
     int bgr_stride = width * 3;
     if (positions) { // the colour image as one linear copy with its own row stride (see ws_search_host)
-        const bool lin = (size_t)bgr->stride <= (size_t)6 * width;
+        const bool lin = linear_span(bgr);
         if (lin) {
             bgr_stride = bgr->stride;
             const size_t span = (size_t)bgr->stride * (height - 1) + (size_t)width * 3;
