@@ -329,6 +329,18 @@ def test_strided_buffers_and_extreme_arguments(wslib, gpu_ctx, oracle):
     assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(NLi), ctypes.byref(NRi), o2.ctypes.data, 71, 0) == 0
     assert lib.ws_wait(gpu_ctx._h) == 0
     assert np.array_equal(o1.astype(np.float64), nwant) and np.array_equal(o2.astype(np.float64), nwant)
+    # a big cut-out of a much wider image (span > 32 MB, > 2 x dense): the row-by-row copy path
+    rng = np.random.default_rng(5)
+    huge_l = rng.integers(1, 255, size=(1900, 6100, 3), dtype=np.uint8)
+    huge_r = np.roll(huge_l, -3, axis=1)
+    cl, cr = huge_l[:, 100:501], huge_r[:, 100:501]
+    cwant = oracle.block_left(np.ascontiguousarray(cl), np.ascontiguousarray(cr), 3, 0, 8, threads=8)
+    CLi = wslib._Image(cl.ctypes.data, 401, 1900, cl.strides[0])
+    CRi = wslib._Image(cr.ctypes.data, 401, 1900, cr.strides[0])
+    p3 = wslib.make_params(wslib.VIEW_LEFT, 3, 0, 8)
+    o3 = np.zeros((1900, 401), dtype=np.float32)
+    assert lib.ws_search_host(gpu_ctx._h, ctypes.byref(p3), ctypes.byref(CLi), ctypes.byref(CRi), o3.ctypes.data, 401, 0) == 0
+    assert np.array_equal(o3.astype(np.float64), cwant)
     # the same through the device entry point with strided device tensors
     tl, tr = torch.from_numpy(big_l).cuda()[5:55, 10:230], torch.from_numpy(big_r).cuda()[5:55, 10:230]
     to = torch.full((50, 256), -5.0, dtype=torch.float32, device="cuda")
