@@ -297,7 +297,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     }
     Canon c{};
     MarchLaunch m{};
-    Plane ring_a{}, ring_b{};
+    Plane ring_a{}, ring_b{}, ring_bi{};
     bool march = make_canon(p, L, R, &c) &&
                  march_plan(c, ctx->num_cus, ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads, &m);
     if (march) {
@@ -312,6 +312,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         pbi.data = static_cast<uint32_t *>(ctx->bias.p);
         ring_a = pa;
         ring_b = pb;
+        ring_bi = pbi;
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
         if (c.mirror) {
@@ -362,7 +363,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ctx->last_skip[2] = ga.skip_y0; ctx->last_skip[3] = ga.skip_y1;
     }
     if (p->subpixel) {
-        if (march) WS_HIP(ctx, launch_refine_planes(c, ring_a, ring_b, out, out_stride, s));
+        if (march) WS_HIP(ctx, launch_refine_planes(c, m, ring_a, ring_b, ring_bi, out, out_stride, s));
         WS_HIP(ctx, launch_refine(ga, s)); // the pixels outside the marching interior (all of them without it)
     }
     return WS_OK;

@@ -93,7 +93,8 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
 // Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // the same for the marching interior, on the packed planes (launch_refine then skips g's skip rectangle)
-hipError_t launch_refine_planes(const Canon &c, Plane a, Plane b, float *out, int out_pitch, hipStream_t s);
+hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias, float *out, int out_pitch,
+                                hipStream_t s); // bias: the marching kernel's bias plane (SSD)
 // smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
