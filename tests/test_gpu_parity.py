@@ -457,6 +457,32 @@ def test_device_resident_path_and_f32_output(wslib, gpu_ctx, oracle):
     assert torch.equal(out, out2)
 
 
+def test_device_entry_point_can_be_captured_into_a_hip_graph(wslib, gpu_ctx):
+    """After one warm-up call (scratch buffers exist) ws_search_device only enqueues kernels on the
+    caller's stream: a stream capture records it and the replay gives the same bits."""
+    import torch
+    left, right, _ = make_pair(500, 200, 64, seed=51)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    for view, s in ((wslib.VIEW_LEFT, 1.0), (wslib.VIEW_RIGHT, 0.9)):
+        p = wslib.make_params(view, 7, 0, 64, s, "ssd")
+        want = torch.empty((200, 500), dtype=torch.float32, device="cuda")
+        out = torch.empty_like(want)
+        gpu_ctx.search_device(p, tl, tr, want, None)
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            gpu_ctx.search_device(p, tl, tr, out, st.cuda_stream)
+            st.synchronize()
+            with torch.cuda.graph(g, stream=st):
+                gpu_ctx.search_device(p, tl, tr, out, st.cuda_stream)
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), view
+
+
 def test_batched_host_path_equals_single_calls(wslib, gpu_ctx):
     pairs = [make_pair(201 + 17 * i, 50 + i, 32, seed=40 + i)[:2] for i in range(7)]   # odd widths, 7 > 2 slots
     p = wslib.make_params(wslib.VIEW_LEFT, 5, 0, 32, 1.0, "sad")
