@@ -36,28 +36,16 @@ struct RingArgs {
     int cost_pitch;
 };
 
-constexpr int kRingRun = 32; // most ring pixels per workgroup: one window sum, then up to kRingRun - 1 slides
+constexpr int kRingTile = 8;                          // a workgroup owns up to 8 x 8 ring pixels
+constexpr int kRingMaxHalf = 8;                       // right-view marching windows: (2 half)^2 <= 16 x 16
+constexpr int kRingCols = kRingTile + 2 * kRingMaxHalf; // window columns under a tile (<= tile + 2 half - 1)
 
-// cost of one window line (n pixels, strides sa / sb: a row or a column of the window)
+// cost of one pixel pair (SSD: without a^2, which is the same for every d)
 template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
-__device__ __forceinline__ int32_t ring_line(const uint32_t *pa, const uint32_t *pb, int n, size_t sa, size_t sb)
+__device__ __forceinline__ int32_t ring_px(uint32_t a, uint32_t b)
 {
-    if constexpr (MODE == 0) {
-        uint32_t acc = 0;
-#pragma unroll 8
-        for (int i = 0; i < n; ++i) acc = pix_sad(pa[i * sa], pb[i * sb], acc);
-        return (int32_t)acc;
-    } else {
-        // sum (a-b)^2 = sum a^2 + [sum b^2 - 2 sum ab]; sum a^2 is the same for every d
-        uint32_t bb = 0, ab = 0;
-#pragma unroll 8
-        for (int i = 0; i < n; ++i) {
-            const uint32_t va = pa[i * sa], vb = pb[i * sb];
-            bb = pix_dot<MODE == 2>(vb, vb, bb);
-            ab = pix_dot<MODE == 2>(va, vb, ab);
-        }
-        return (int32_t)bb - 2 * (int32_t)ab;
-    }
+    if constexpr (MODE == 0) return (int32_t)pix_sad(a, b, 0u);
+    else return (int32_t)pix_dot<MODE == 2>(b, b, 0u) - 2 * (int32_t)pix_dot<MODE == 2>(a, b, 0u);
 }
 
 // The clipped window of ring pixel (x, y), original coordinates -> canonical columns [ca, ce), rows [ra, re)
@@ -74,94 +62,154 @@ __device__ __forceinline__ RingWin ring_window(const RingArgs &g, int x, int y)
     return w;
 }
 
-// One workgroup = a run of kRingRun ring pixels along a row (top / bottom band) or along a column
-// (side bands); its four waves take every fourth group of 64 consecutive disparities (lane = d).
-// The first pixel's window is summed in full, every next one is the previous one minus the line
-// that left plus the line that entered (the clipped windows of neighbouring ring pixels differ by
-// at most one line at either end).  The costs of a group go to LDS ([d][pixel], padded), then lane
-// (pixel, half) scans 32 disparities in ascending order -- the reference's tie rule -- and the
-// groups meet in one 64-bit LDS min per pixel.
-template <int MODE>
-__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int n_hruns, int hruns_per_row, int vruns_per_col, int rl)
+// A small marching kernel for the ring.  A workgroup owns a tile of up to 8 x 8 ring pixels; its
+// 256 threads are 256 consecutive disparities (per round).  Every thread keeps the COLUMN sums of
+// its disparity's costs over the current row's window rows, for the <= 23 window columns under the
+// tile (the plane strips under the tile are staged in LDS).  Going down a row, a column sum gains the row that enters the (clipped) window and
+// loses the one that leaves -- at the top of the image rows only enter, at the bottom they only
+// leave, beside it both -- and a pixel's window cost is the sum of its (clipped) column range, a
+// difference of two prefix sums.  So a hypothesis costs about three pixel
+// operations instead of a whole window.  Per row the costs go to LDS ([d][pixel], padded), lane
+// (pixel, part) scans 8 disparities in ascending order -- the reference's tie rule -- and
+// everything meets in one 64-bit LDS min per pixel.
+template <int MODE, int NCOLS> // NCOLS >= tile + 2 half - 1 window columns under a tile: 16 (half <= 4) or 24
+__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtiles, int seg_top, int seg_bot, int xt_left,
+                                                      int xt_right, int seg_mid)
 {
-    __shared__ int32_t costs[4][64][kRingRun + 1];
-    __shared__ long long best[kRingRun];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // the run is the same for the whole workgroup: every address derived from it stays in scalar
-    // registers, so the window of plane A is fetched by scalar loads
-    const int run = blockIdx.x;
-    const bool horizontal = run < n_hruns;
-    int x0, y0, n;
-    if (horizontal) {
-        const int rowi = run / hruns_per_row;
-        y0 = rowi < g.skip_y0 ? rowi : g.skip_y1 + (rowi - g.skip_y0);
-        x0 = (run % hruns_per_row) * rl;
-        n = min(rl, g.wa - x0);
+    extern __shared__ uint32_t ring_lds[]; // the tile's strips of plane A and plane B
+    __shared__ int32_t prefix[NCOLS + 1][256];
+    __shared__ int32_t costs[4][64][kRingTile + 1];
+    __shared__ long long best[kRingTile * kRingTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // which tile: the bands above and below the marching interior over the whole width, then the
+    // columns left and right of it
+    int b = blockIdx.x, x0, y0, nx, ny;
+    const int n_band = (seg_top + seg_bot) * xtiles;
+    if (b < n_band) {
+        const int seg = b / xtiles;
+        x0 = (b - seg * xtiles) * kRingTile;
+        nx = min(kRingTile, g.wa - x0);
+        if (seg < seg_top) { y0 = seg * kRingTile; ny = min(kRingTile, g.skip_y0 - y0); }
+        else { y0 = g.skip_y1 + (seg - seg_top) * kRingTile; ny = min(kRingTile, g.ha - y0); }
     } else {
-        const int v = run - n_hruns, coli = v / vruns_per_col;
-        x0 = coli < g.skip_x0 ? coli : g.skip_x1 + (coli - g.skip_x0);
-        y0 = g.skip_y0 + (v % vruns_per_col) * rl;
-        n = min(rl, g.skip_y1 - y0);
+        b -= n_band;
+        const int xt = xt_left + xt_right, seg = b / xt, t = b - seg * xt;
+        if (t < xt_left) { x0 = t * kRingTile; nx = min(kRingTile, g.skip_x0 - x0); }
+        else { x0 = g.skip_x1 + (t - xt_left) * kRingTile; nx = min(kRingTile, g.wa - x0); }
+        y0 = g.skip_y0 + seg * kRingTile;
+        ny = min(kRingTile, g.skip_y1 - y0);
     }
-    if (threadIdx.x < kRingRun) best[threadIdx.x] = LLONG_MAX;
-    __syncthreads();
-    const size_t pa_ = g.pitch_a, pb_ = g.pitch_b;
-    for (int dbase = g.d_lo + 64 * wave; dbase <= g.d_hi; dbase += 256) {
-        const int d = dbase + lane;
-        int32_t cost = 0;
-        RingWin w{};
-        bool have = false; // cost holds the window w for the lanes whose d is a candidate there
-        const uint32_t *A0 = g.A + g.pad_a, *B0 = g.B + (g.boff + g.pad_b - d);
-        for (int i = 0; i < n; ++i) {
-            const int x = horizontal ? x0 + i : x0, y = horizontal ? y0 : y0 + i;
-            const RingWin nw = ring_window(g, x, y);
-            const bool empty = nw.ce <= nw.ca || nw.re <= nw.ra; // 0/0 = NaN never wins (BlockSearch.cpp:158)
-            const bool valid = !empty && d <= nw.d_end; // candidates only drop out along a run, never join
-            if (valid) {
-                if (!have) {
-                    cost = 0;
-                    for (int r = nw.ra; r < nw.re; ++r)
-                        cost += ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
-                } else if (horizontal) { // x + 1: the canonical window moves towards lower columns
-                    for (int c = nw.ce; c < w.ce; ++c)
-                        cost -= ring_line<MODE>(A0 + nw.ra * pa_ + c, B0 + nw.ra * pb_ + c, nw.re - nw.ra, pa_, pb_);
-                    for (int c = nw.ca; c < w.ca; ++c)
-                        cost += ring_line<MODE>(A0 + nw.ra * pa_ + c, B0 + nw.ra * pb_ + c, nw.re - nw.ra, pa_, pb_);
-                } else { // y + 1
-                    for (int r = w.ra; r < nw.ra; ++r)
-                        cost -= ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
-                    for (int r = w.re; r < nw.re; ++r)
-                        cost += ring_line<MODE>(A0 + r * pa_ + nw.ca, B0 + r * pb_ + nw.ca, nw.ce - nw.ca, 1, 1);
+    // canonical window columns under the tile (they fall as x rises) and window rows (they rise with y)
+    const RingWin wfirst = ring_window(g, x0, y0), wlast = ring_window(g, x0 + nx - 1, y0);
+    const int CA = min(wfirst.ca, wlast.ca), CE = max(wfirst.ce, wlast.ce);
+    const int nc = min(max(CE - CA, 0), NCOLS);
+    const int RA = wfirst.ra, RE = max(ring_window(g, x0, y0 + ny - 1).re, RA);
+    const int nr = min(RE - RA, NCOLS);
+    // the strips of both planes under the tile's windows go through LDS: A once, B per round of 256
+    // disparities (columns c - d + boff for c in [CA, CE), d in [dblk, dtop])
+    uint32_t *sA = ring_lds, *sB = ring_lds + nc * nr;
+    for (int i = tid; i < nc * nr; i += 256) {
+        const int r = i / nc, c = i - r * nc;
+        sA[i] = g.A[(size_t)(RA + r) * g.pitch_a + (CA + c + g.pad_a)]; // (the windows lie inside the image)
+    }
+    if (tid < kRingTile * kRingTile) best[tid] = LLONG_MAX;
+    for (int dblk = g.d_lo; dblk <= g.d_hi; dblk += 256) {
+        const int dtop = min(dblk + 255, g.d_hi);
+        const int CB = CA - dtop + g.boff, WB = nc + (dtop - dblk);
+        __syncthreads(); // (the previous round's readers are done with sB; first round: sA / best are written)
+        for (int i = tid; i < WB * nr; i += 256) {
+            const int r = i / WB, c = CB + (i - r * WB) + g.pad_b;
+            sB[i] = c >= 0 && c < g.pitch_b ? g.B[(size_t)(RA + r) * g.pitch_b + c] : 0u;
+        }
+        __syncthreads();
+        const int d = dblk + tid;
+        // A0[r * nc + c] / B0[r * WB + c]: the planes at window row RA + r, window column CA + c (B shifted by d);
+        // a thread beyond d_hi reads in-bounds garbage (clamped shift) that no candidate test accepts
+        const uint32_t *A0 = sA, *B0 = sB + max(dtop - d, 0);
+        // the column sums stay in registers; everything below is unrolled over the NCOLS columns
+        // (clamped index: columns past nc repeat the last one and are never summed) so that a row's
+        // LDS reads are all in flight together -- the tile is latency-, not throughput-bound
+        int32_t sum[NCOLS];
+        int ra = 0, re = 0;
+        for (int j = 0; j < ny; ++j) {
+            const int y = y0 + j;
+            const RingWin wr = ring_window(g, x0, y); // (the window rows do not depend on x)
+            const int r0 = wr.ra - RA, r1 = max(wr.re - RA, r0);
+            // 1. column sums of the window rows [r0, r1)
+            if (j == 0) {
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) sum[c] = 0;
+                for (int r = r0; r < r1; ++r) {
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        const int cc = min(c, nc - 1);
+                        sum[c] += ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                    }
+                }
+            } else {
+                for (int r = ra; r < r0; ++r) { // rows that left the window (at most one)
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        const int cc = min(c, nc - 1);
+                        sum[c] -= ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                    }
+                }
+                for (int r = re; r < r1; ++r) { // rows that entered it (at most one)
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) {
+                        const int cc = min(c, nc - 1);
+                        sum[c] += ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                    }
                 }
             }
-            have = !empty;
-            w = nw;
-            costs[wave][lane][i] = valid ? cost : INT_MAX; // (a real cost stays far below INT_MAX)
-        }
-        // this wave's 64 disparities of pixel p: two lanes scan 32 each, ascending d, strict '<'
-        const int p = lane & 31, part = lane >> 5;
-        int32_t bc = INT_MAX;
-        int bd = 0;
-        if (p < n) {
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const int32_t c = costs[wave][part * 32 + k][p];
-                if (c < bc) { bc = c; bd = dbase + part * 32 + k; }
+            ra = r0; re = r1;
+            // prefix sums over the columns, to LDS for the pixels' (run-time) column ranges
+            {
+                int32_t acc = 0;
+                prefix[0][tid] = 0;
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    acc += sum[c];
+                    prefix[c + 1][tid] = acc;
+                }
             }
-            if (bc != INT_MAX) atomicMin(&best[p], ((long long)bc << 32) | (uint32_t)bd); // ties: smaller d
+            // 2. the row's pixels: window cost = prefix[ce] - prefix[ca]
+#pragma unroll
+            for (int i = 0; i < kRingTile; ++i) {
+                const RingWin w = ring_window(g, x0 + min(i, nx - 1), y);
+                const bool empty = w.ce <= w.ca || w.re <= w.ra; // 0/0 = NaN never wins (BlockSearch.cpp:158)
+                const int ca = min(max(w.ca - CA, 0), nc), ce = min(max(w.ce - CA, 0), nc);
+                const int32_t wsum = prefix[ce][tid] - prefix[ca][tid];
+                const bool valid = !empty && d <= w.d_end;
+                costs[wave][lane][i] = valid ? wsum : INT_MAX; // (a real cost stays far below INT_MAX)
+            }
+            // 3. this wave's 64 disparities of pixel p: lanes (p, part) scan 8 each, ascending d, strict '<'
+            const int p = lane & 7, part = lane >> 3;
+            if (p < nx) {
+                int32_t bc = INT_MAX;
+                int bd = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int32_t c = costs[wave][part * 8 + k][p];
+                    if (c < bc) { bc = c; bd = dblk + 64 * wave + part * 8 + k; }
+                }
+                if (bc != INT_MAX) atomicMin(&best[j * kRingTile + p], ((long long)bc << 32) | (uint32_t)bd); // ties: smaller d
+            }
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n) {
-        const int i = threadIdx.x;
-        const int x = horizontal ? x0 + i : x0, y = horizontal ? y0 : y0 + i;
-        const uint32_t black = MODE == 2 ? kCentre : 0u;
-        float val = 0.0f;
-        if (y < g.height && g.A[(size_t)y * g.pitch_a + (g.wa - 1 - x) + g.pad_a] != black)
-            val = best[i] == LLONG_MAX ? -(float)x : (float)(uint32_t)(best[i] & 0xffffffffll);
-        g.out[(size_t)y * g.out_pitch + x] = val;
-        if (g.cost_out && best[i] != LLONG_MAX) g.cost_out[(size_t)y * g.cost_pitch + x] = (int32_t)(best[i] >> 32);
+    if (tid < kRingTile * kRingTile) {
+        const int i = tid & 7, j = tid >> 3;
+        if (i < nx && j < ny) {
+            const int x = x0 + i, y = y0 + j;
+            const uint32_t black = MODE == 2 ? kCentre : 0u;
+            const long long k = best[j * kRingTile + i];
+            float val = 0.0f;
+            if (y < g.height && g.A[(size_t)y * g.pitch_a + (g.wa - 1 - x) + g.pad_a] != black)
+                val = k == LLONG_MAX ? -(float)x : (float)(uint32_t)(k & 0xffffffffll);
+            g.out[(size_t)y * g.out_pitch + x] = val;
+            if (g.cost_out && k != LLONG_MAX) g.cost_out[(size_t)y * g.cost_pitch + x] = (int32_t)(k >> 32);
+        }
     }
 }
 
@@ -183,19 +231,21 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
     }
     g.out = out; g.out_pitch = out_pitch;
     g.cost_out = cost_out; g.cost_pitch = cost_pitch;
-    // run length: long runs amortise the first full window, short ones give more workgroups
-    int rl = 8; // (measured 4 .. 32 at 7x7, 11x11, 17x17: flat between 4 and 16)
-    if (const char *e = getenv("WS_RING_RUN")) rl = std::max(1, std::min(kRingRun, atoi(e))); // development knob
-    const int hruns_per_row = ceil_div(c.wa, rl);
-    const int n_hruns = (g.skip_y0 + (c.ha - g.skip_y1)) * hruns_per_row;
-    const int vruns_per_col = ceil_div(g.skip_y1 - g.skip_y0, rl);
-    const int n_vruns = (g.skip_x0 + (c.wa - g.skip_x1)) * vruns_per_col;
-    if (n_hruns + n_vruns <= 0) return hipSuccess;
-    dim3 grid((unsigned)(n_hruns + n_vruns));
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, g, n_hruns, hruns_per_row, vruns_per_col, rl); };
-    if (!g.ssd) launch(ws_ring_kernel<0>);
-    else if (!g.centred) launch(ws_ring_kernel<1>);
-    else launch(ws_ring_kernel<2>);
+    if (g.half > kRingMaxHalf) return hipErrorInvalidValue;
+    const int xtiles = ceil_div(c.wa, kRingTile);
+    const int seg_top = ceil_div(g.skip_y0, kRingTile), seg_bot = ceil_div(c.ha - g.skip_y1, kRingTile);
+    const int xt_left = ceil_div(g.skip_x0, kRingTile), xt_right = ceil_div(c.wa - g.skip_x1, kRingTile);
+    const int seg_mid = ceil_div(g.skip_y1 - g.skip_y0, kRingTile);
+    const long long blocks = (long long)(seg_top + seg_bot) * xtiles + (long long)(xt_left + xt_right) * seg_mid;
+    if (blocks <= 0) return hipSuccess;
+    dim3 grid((unsigned)blocks);
+    const int side = kRingTile + 2 * g.half; // >= window columns and window rows under a tile
+    const size_t lds = (size_t)(side * side + side * (side + 255)) * sizeof(uint32_t);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, g, xtiles, seg_top, seg_bot, xt_left, xt_right, seg_mid); };
+    const bool narrow = kRingTile + 2 * g.half - 1 <= 16;
+    if (!g.ssd) narrow ? launch(ws_ring_kernel<0, 16>) : launch(ws_ring_kernel<0, kRingCols>);
+    else if (!g.centred) narrow ? launch(ws_ring_kernel<1, 16>) : launch(ws_ring_kernel<1, kRingCols>);
+    else narrow ? launch(ws_ring_kernel<2, 16>) : launch(ws_ring_kernel<2, kRingCols>);
     return hipGetLastError();
 }
 
