@@ -209,10 +209,15 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
 template <bool SSD, bool CENTRED>
 __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const PreparePlanesArgs g)
 {
+    // one wave per ring pixel: the lanes share the (clipped) window's pixels, wave-wide sums
+    // (26 k waves; 16 pixels per wave in turn, with one thread per pixel for the decision, measured
+    // slower: 26 vs 18 us -- the window sums are latency-bound and want the parallelism)
     GenericArgs e{}; // only the skip rectangle is used by ring_pixel
     e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int x, y; // original coordinates
-    if (!ring_pixel(e, g.wa, g.ha, (long long)blockIdx.x * blockDim.x + threadIdx.x, &x, &y)) return;
+    if (!ring_pixel(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
     const int xm = g.wa - 1 - x;
     float *o = g.out + (size_t)y * g.out_pitch + x;
     uint8_t code = kSelFixed;
@@ -228,35 +233,37 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
             val = 0.0f; // d = 0 is the only candidate
         } else {
             const int ca = xm - right + 1; // first window column, canonical
-            long long c0 = 0, sa = 0;
-            for (int r = y - up; r < y + down; ++r) {
-                const uint32_t *pa = g.A + (size_t)r * g.pitch_a + ca + g.pad_a;
-                const uint32_t *pb = g.B + (size_t)r * g.pitch_b + ca + g.boff + g.pad_b;
-                uint32_t aa = 0, bb = 0, ab = 0;
-                for (int i = 0; i < ww; ++i) {
-                    if constexpr (SSD) {
-                        aa = pix_dot<CENTRED>(pa[i], pa[i], aa);
-                        bb = pix_dot<CENTRED>(pb[i], pb[i], bb);
-                        ab = pix_dot<CENTRED>(pa[i], pb[i], ab);
-                    } else {
-                        ab = pix_sad(pa[i], pb[i], ab);
-                    }
-                }
+            const uint32_t *pa0 = g.A + (size_t)(y - up) * g.pitch_a + ca + g.pad_a;
+            const uint32_t *pb0 = g.B + (size_t)(y - up) * g.pitch_b + ca + g.boff + g.pad_b;
+            uint32_t aa = 0, bb = 0, ab = 0; // a lane sees at most (16 * 16) / 64 pixels: 32 bits hold
+            for (int i = lane; i < ww * wh; i += 64) {
+                const int r = i / ww, c = i - r * ww;
+                const uint32_t a = pa0[(size_t)r * g.pitch_a + c], b = pb0[(size_t)r * g.pitch_b + c];
                 if constexpr (SSD) {
-                    c0 += (long long)(int32_t)aa + (int32_t)bb - 2LL * (int32_t)ab;
-                    sa += (int32_t)aa;
+                    aa = pix_dot<CENTRED>(a, a, aa);
+                    bb = pix_dot<CENTRED>(b, b, bb);
+                    ab = pix_dot<CENTRED>(a, b, ab);
                 } else {
-                    c0 += ab;
+                    ab = pix_sad(a, b, ab);
                 }
+            }
+            long long c0, sa = 0;
+            if constexpr (SSD) {
+                c0 = (long long)wave_sum_u64((unsigned long long)((long long)(int32_t)aa + (int32_t)bb - 2LL * (int32_t)ab));
+                sa = (long long)wave_sum_u64((unsigned long long)(long long)(int32_t)aa);
+            } else {
+                c0 = (long long)wave_sum_u64((unsigned long long)ab);
             }
             val = *o;
             const long long c1 = (long long)g.cost[(size_t)y * g.cost_pitch + x] + sa;
             code = smooth_code<SSD>(c0, c1, (double)(ww * wh), g.s);
         }
     }
-    *o = val;
-    if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
-    g.sel[(size_t)y * g.sel_pitch + x] = code;
+    if (lane == 0) {
+        *o = val;
+        if ((code & kSelFixed) && val == 0.0f) code |= kSelZero;
+        g.sel[(size_t)y * g.sel_pitch + x] = code;
+    }
 }
 
 // compose two maps {0,1}->{0,1} stored as bit0 = f(0), bit1 = f(1):  (b o a)(v) = b(a(v))
@@ -958,7 +965,7 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
         dim3 gi(ceil_div(canon->ox1 - canon->ox0, 64), ceil_div(canon->oy1 - canon->oy0, kBoxRows));
         const long long inside = (long long)(g.skip_x1 - g.skip_x0) * (g.skip_y1 - g.skip_y0);
         const long long nring = (long long)canon->wa * canon->ha - (inside > 0 ? inside : 0);
-        dim3 gr((unsigned)ceil_div((int)nring, 256));
+        dim3 gr((unsigned)ceil_div((int)nring, 4)); // a wave per ring pixel, 4 per workgroup
         if (!canon->ssd) {
             hipLaunchKernelGGL((ws_smooth_prepare_box_kernel<false, false>), gi, dim3(256), 0, st, a);
             if (nring > 0) hipLaunchKernelGGL((ws_smooth_prepare_ring_kernel<false, false>), gr, dim3(256), 0, st, a);
