@@ -4,18 +4,27 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work: started WITHOUT a torch.distributed environment and with --gpus N > 1, this
+process only launches the N ranks (fresh child processes, before anything here touches a GPU),
+waits for them and passes rank 0's JSON line through.
+
 A "step" is one pass of the hot path (BlockSearch::computeDisparityMapLeft,
 BlockSearch.cpp:24-86, through the C-ABI ws_search_device) over one synthetic
 Middlebury-H-shaped pair that is already resident in HBM: BASELINE.json configs[1]
 = 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0.  With N ranks every rank
 owns its own pair (independent pairs shard with no collective: weak scaling); the
-barrier / all_reduce(MAX) below only brackets the timing.
+barrier / all_reduce(MAX) below only brackets the timing.  `--workload config4` is
+BASELINE.json configs[3]: the 15 trainingH-shaped pairs sharded over the ranks (strong).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
 (ws_march_kernel): algorithmic bytes per launch / its average duration measured
 with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
 (oracle/, a port: the reference itself cannot be built here) on a bounded row band
-of the same workload on this box's host cores.
+of the same workload on this box's host cores, all cores and one core (the reference
+is single-threaded).  `e2e` is what a caller of the boundary gets from ONE
+ws_search_host call incl. H2D/D2H (never `value`).  `quality` is bad-2.0 (evaldisp,
+utils.cpp:123-168) of the device map and of the oracle's map on the two trainingH
+scenes whose ground truth the reference tree holds (fixtures under tests/golden/).
 """
 import argparse
 import json
@@ -23,12 +32,11 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_ROUND = "r02"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
 
 WORKLOADS = {
     # name: (width, height, block, cost, maxD, seed)
@@ -53,36 +61,74 @@ def host_cores():
     return n
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=256, help="rows of the CPU baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e and quality legs (profiling runs)")
+    ap.add_argument("--cpu-rows", type=int, default=1000,
+                    help="rows of the all-cores CPU baseline sample (1/16 of it for the one-core sample)")
     ap.add_argument("--check", action="store_true", help="compare a row band with the oracle")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import stereo_reconstruction_amd as ws
-    from stereo_reconstruction_amd.synthetic import make_pair
 
+def launch_ranks(n, argv):
+    """Start the n ranks as fresh child processes (this process has not touched a GPU and never
+    will), one per GPU, wait for them, return the job's exit code.  Rank 0 writes the JSON line to
+    the inherited stdout.  A rank that dies takes the others down instead of leaving them at a barrier."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:       # the exact processes started above
+                    q.terminate()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    args.gpus = world
     # WS_BENCH_REHEARSE=1: rehearse the N>1 code path on a box with fewer GPUs than ranks (all
-    # ranks share the devices round-robin, gloo instead of RCCL).  Never used for reported numbers.
-    rehearse = os.environ.get("WS_BENCH_REHEARSE") == "1"
-    if rehearse:
+    # ranks share the devices round-robin, gloo instead of RCCL).  =dry: no device at all, the
+    # step is a stand-in (CPU test of the launcher and the rank plumbing).  Never for reported numbers.
+    rehearse = os.environ.get("WS_BENCH_REHEARSE", "")
+    dry = rehearse == "dry"
+
+    import torch
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    if rehearse and not dry:
         local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    if not dry:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -92,49 +138,61 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import stereo_reconstruction_amd as ws
+    from stereo_reconstruction_amd.synthetic import make_pair
     # the extension normally travels with the tree; a tree without it gets it built once per node
     from stereo_reconstruction_amd import build as ws_build
     if not os.path.exists(os.environ.get("WS_STEREO_LIB", ws_build.LIB)):
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        if local_rank == 0:
             ws_build.build()
         if dist is not None:
             dist.barrier()
-    dev = torch.device("cuda", local_rank)
-    ctx = ws.WindowSearch(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    ctx = None if dry else ws.WindowSearch(local_rank)
+    stream = None if dry else torch.cuda.current_stream().cuda_stream
     batch = args.workload == "config4"
     if batch:
         from stereo_reconstruction_amd.sharding import lpt_assign
         from stereo_reconstruction_amd.synthetic import TRAINING_H
         bs, cost, max_d = 7, "ssd", 256
         shapes = [(w, h) for _, w, h, _ in TRAINING_H]
-        mine = lpt_assign([w * h * max_d for w, h in shapes], world)[rank]
-        pairs = []
-        for i in mine:
-            l, r, _ = make_pair(shapes[i][0], shapes[i][1], max_d, 100 + i)
-            pairs.append((torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev),
-                          torch.empty((shapes[i][1], shapes[i][0]), dtype=torch.float32, device=dev)))
-        width, height = shapes[mine[0]] if mine else shapes[0]
-        left, right = (pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy()) if pairs else (None, None)
-        t_out = pairs[0][2] if pairs else None
+        mine = lpt_assign([w * h * max_d for w, h in shapes], world)[rank]   # may be empty (world > 15)
+        todo = [(shapes[i][0], shapes[i][1], 100 + i) for i in mine]
         hyps_total = float(sum(w * h * max_d for w, h in shapes))
+        width, height = shapes[0]
     else:
         width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
-        left, right, _gt = make_pair(width, height, max_d, seed + rank)
-        t_out = torch.empty((height, width), dtype=torch.float32, device=dev)
-        pairs = [(torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev), t_out)]
+        mine = [rank]
+        todo = [(width, height, seed + rank)]
         hyps_total = float(width) * height * max_d * world   # one pair per rank (weak scaling)
-    params = ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
+    host_pairs, pairs = [], []
+    for w, h, sd in todo:
+        if dry:
+            host_pairs.append((None, None))
+            pairs.append((w, h))
+            continue
+        l, r, _ = make_pair(w, h, max_d, sd)
+        host_pairs.append((l, r))
+        pairs.append((torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev),
+                      torch.empty((h, w), dtype=torch.float32, device=dev)))
+    params = None if dry else ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
 
     def step():
+        if dry:
+            time.sleep(1e-3 * len(pairs))
+            return
         for tl, tr, to in pairs:   # whole pairs per rank, no collective on the data path
             ctx.search_device(params, tl, tr, to, stream)
 
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -151,91 +209,171 @@ def main():
 
     value = hyps_total * args.steps / elapsed / 1e6     # H*W*D hypotheses of the whole job
 
-    # dominant kernel, timed alone with HIP events on the launch stream
-    kernel_ms = None
-    info = ctx.last_launch()
-    ctx.set_profiling(True)
-    acc = []
-    for _ in range(min(args.steps, 20)):
-        step()
-        acc.append(ctx.last_kernel_ms())
-    ctx.set_profiling(False)
-    kernel_ms = float(np.mean(acc))
-    # the event pair brackets the LAST pair's marching kernel of a step
-    lw, lh = pairs[-1][0].shape[1], pairs[-1][0].shape[0]
-    alg_bytes = 3.0 * lh * lw + 3.0 * pairs[-1][1].shape[0] * pairs[-1][1].shape[1] + 4.0 * lh * lw
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # dominant kernel, timed alone with HIP events on the launch stream: every pair of this rank
+    reps = max(1, min(args.steps, 20))
+    kernel_ms = [0.0] * len(pairs)     # average duration of the marching kernel, per pair of this rank
+    info = {"kernel": "", "threads": 0, "workgroups": 0, "lds_bytes": 0}
+    if not dry and pairs:
+        ctx.set_profiling(True)
+        for _ in range(reps):
+            for i, (tl, tr, to) in enumerate(pairs):
+                ctx.search_device(params, tl, tr, to, stream)
+                kernel_ms[i] += ctx.last_kernel_ms() / reps
+        ctx.set_profiling(False)
+        info = ctx.last_launch()
+    alg_bytes = [3.0 * h * w + 3.0 * h * w + 4.0 * h * w for (w, h, _) in todo]   # both images + the f32 map
+    summary = {"rank": rank, "pairs": list(mine), "kernel_ms_sum": round(sum(kernel_ms), 4),
+               "alg_bytes": sum(alg_bytes), "hyps": float(sum(w * h * max_d for w, h, _ in todo))}
+    if dist is not None:
+        summaries = [None] * world
+        dist.all_gather_object(summaries, summary)
+    else:
+        summaries = [summary]
 
-    # HBM traffic of the dominant kernel: measured separately with rocprofv3 --pmc (one pass per
-    # counter) and committed; bench.py does not run the profiler itself
-    traffic, valu = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01", "traffic_%s.json" % args.workload)
-    if os.path.exists(tfile):
-        tj = json.load(open(tfile))
-        if tj.get("kernel") == info["kernel"]:
-            traffic = tj["hbm_bytes_per_launch"]
-            if "sq_insts_valu" in tj:
-                # the bound that actually applies: VALU instruction issue
-                lane_ops = tj["sq_insts_valu"] * 64.0
-                valu = {"lane_ops_per_launch": lane_ops,
-                        "lane_ops_per_hypothesis": round(lane_ops / (float(lw) * lh * max_d), 2),
-                        "achieved_lane_ops_per_s": round(lane_ops / (kernel_ms * 1e-3), 0),
-                        "measured_issue_peak_lane_ops_per_s": tj["valu_issue_peak_lane_ops_per_s"],
-                        "frac": round(lane_ops / (kernel_ms * 1e-3) / tj["valu_issue_peak_lane_ops_per_s"], 3)}
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel over the launches of the busiest rank (config 2: the one launch)
+        busiest = max(summaries, key=lambda s: s["kernel_ms_sum"])
+        k_ms, k_bytes = busiest["kernel_ms_sum"], busiest["alg_bytes"]
+        n_launch = max(1, len(busiest["pairs"]))
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # HBM traffic / VALU instructions of the dominant kernel: measured with rocprofv3 --pmc (separate
+        # passes), summarised by tools/pmc_to_traffic.py into profiles/<round>/; bench.py does not run the profiler
+        traffic, valu = None, None
+        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_%s.json" % args.workload)
+        if os.path.exists(tfile) and k_ms > 0:
+            tj = json.load(open(tfile))
+            if tj.get("kernel") == info["kernel"]:
+                traffic = tj["hbm_bytes_per_launch"]
+                if "sq_insts_valu" in tj:
+                    # the bound that actually applies: VALU instruction issue
+                    lane_ops = tj["sq_insts_valu"] * 64.0
+                    per_launch_ms = k_ms / n_launch
+                    valu = {"lane_ops_per_launch": lane_ops,
+                            "lane_ops_per_hypothesis": round(lane_ops / (busiest["hyps"] / n_launch), 2),
+                            "achieved_lane_ops_per_s": round(lane_ops / (per_launch_ms * 1e-3), 0),
+                            "measured_issue_peak_lane_ops_per_s": tj["valu_issue_peak_lane_ops_per_s"],
+                            "frac": round(lane_ops / (per_launch_ms * 1e-3) / tj["valu_issue_peak_lane_ops_per_s"], 3),
+                            "source": "profiles/%s/traffic_%s.json" % (PROFILE_ROUND, args.workload)}
+        out = {
+            "metric": "Mdisparities/s (HxWxD / s) on Middlebury-H pairs",
+            "value": round(value, 1),
+            "unit": "Mdisparities/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong" if batch else "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic" + ((" (REHEARSAL: %s)" % ("no device, stand-in step" if dry else "ranks share GPUs, gloo"))
+                                   if rehearse else ""),
+            "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
+                                    "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
+                                   "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
+                                   % (args.workload, width, height, bs, bs, cost.upper(), max_d),
+                       "pairs_per_step": 15 if batch else world, "sharding": "independent pairs, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": info["kernel"], "kernel_ms": round(k_ms / n_launch, 4),
+                         "launches": n_launch, "algorithmic_bytes": k_bytes / n_launch, "valu_issue": valu,
+                         "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "
+                                 "VALU-issue bound, see DESIGN.md for the lane-op ceiling"},
+        }
+        if batch or world > 1:
+            out["per_rank"] = [{"rank": s["rank"], "pairs": len(s["pairs"]), "kernel_ms_sum": s["kernel_ms_sum"],
+                                "Mdisp": round(s["hyps"] / 1e6, 1)} for s in summaries]
 
-    out = {
-        "metric": "Mdisparities/s (HxWxD / s) on Middlebury-H pairs",
-        "value": round(value, 1),
-        "unit": "Mdisparities/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "strong" if batch else "weak",
-        "vs_baseline": None,
-        "dtype": "u8",
-        "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
-        "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
-                                "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
-                               "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
-                               % (args.workload, width, height, bs, bs, cost.upper(), max_d),
-                   "pairs_per_step": 15 if batch else world, "sharding": "independent pairs, no collective"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": info["kernel"], "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes": alg_bytes, "valu_issue": valu,
-                     "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "
-                             "VALU-issue bound, see DESIGN.md for the lane-op ceiling"},
-    }
-
-    if args.check and rank == 0:
+    single = rank == 0 and world == 1 and not dry
+    left, right = host_pairs[0] if host_pairs else (None, None)
+    if args.check and single:
         from oracle import oracle
         y0 = height // 2
-        ref = oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=(y0, y0 + 8),
-                                threads=host_cores())
-        got = t_out[y0:y0 + 8].cpu().numpy().astype(np.float64)
+        ref = oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=(y0, y0 + 8), threads=host_cores())
+        got = pairs[0][2][y0:y0 + 8].cpu().numpy().astype(np.float64)
         out["check_rows_equal"] = bool(np.array_equal(got, ref[y0:y0 + 8]))
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle
-        cores = host_cores()
-        half = (bs - 1) // 2
-        rows = (half, min(height - half, half + args.cpu_rows))
-        t0 = time.perf_counter()
-        oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=rows, threads=cores)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": round((rows[1] - rows[0]) * width * max_d / dt / 1e6, 2),
-            "unit": "Mdisparities/s", "cores": cores, "kind": "port",
-            "sample": "rows [%d,%d) of the same pair (%.0f%% of it), oracle/ws_oracle.c row-parallel "
-                      "over %d threads, %.1f s" % (rows[0], rows[1], 100.0 * (rows[1] - rows[0]) / height,
-                                                  cores, dt)}
+    if single and not args.no_extras and not batch:
+        out["e2e"] = e2e_leg(ws, ctx, params, left, right, width, height, max_d)
+        q = quality_leg(ws, ctx)
+        if q is not None:
+            out["quality"] = q
+
+    if single and not args.no_cpu_baseline and not batch:
+        out["cpu_baseline"] = cpu_baseline_leg(left, right, bs, cost, max_d, width, height, args.cpu_rows)
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def e2e_leg(ws, ctx, params, left, right, width, height, max_d):
+    """One boundary call as the reference's caller makes it: host images in, host map out
+    (ws_search_host; CV_64F as BlockSearch returns it, and f32), PCIe both ways included."""
+    import numpy as np
+    res = {"what": "one ws_search_host call, pageable host buffers, H2D + kernels + D2H + sync; median of 15"}
+    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+        for _ in range(3):
+            ctx.search(params, left, right, dtype=dt)
+        ts = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            ctx.search(params, left, right, dtype=dt)
+            ts.append(time.perf_counter() - t0)
+        ms = float(np.median(ts)) * 1e3
+        res[name] = {"ms_per_call": round(ms, 4), "Mdisparities_per_s": round(width * height * max_d / ms / 1e3, 1)}
+    return res
+
+
+def quality_leg(ws, ctx):
+    """bad-2.0 of the left-view map at the reference's own scale: 7x7 SSD, D = ndisp of calib.txt, on
+    Teddy-H (the scene main.cpp:20 runs) and ArtL; device map vs oracle map (also compared bit for bit)."""
+    import numpy as np
+    from oracle import oracle
+    res = {}
+    for scene, fn in (("Teddy", "teddyH_pair.npz"), ("ArtL", "artL_pair.npz")):
+        path = os.path.join(ROOT, "tests", "golden", fn)
+        if not os.path.exists(path):
+            return None
+        z = np.load(path)
+        l, r, gt, mask, nd = z["left"], z["right"], z["gt"], z["mask"], int(z["ndisp"])
+        got = ws.BlockSearch(l, r, 7, 0, nd, cost="ssd", context=ctx).computeDisparityMapLeft(1.0)
+        want = oracle.block_left(l, r, 7, 0, nd, cost="ssd", threads=host_cores())
+        eg = ws.evaldisp(got, gt, mask, 2.0, float(nd))
+        ec = oracle.evaldisp(want, gt, mask, 2.0, float(nd))
+        res[scene] = {"shape": [int(l.shape[1]), int(l.shape[0])], "ndisp": nd,
+                      "bad2.0_gpu": round(eg["bad"], 4), "bad2.0_cpu": round(ec["bad"], 4),
+                      "maps_identical": bool(np.array_equal(got, want))}
+    res["what"] = "evaldisp(map, disp0GT, mask0nocc, 2.0, ndisp, 0) 'bad' percent, left view 7x7 SSD (utils.cpp:123-168)"
+    return res
+
+
+def cpu_baseline_leg(left, right, bs, cost, max_d, width, height, cpu_rows):
+    """The CPU oracle (a port of BlockSearch.cpp:24-86) on row bands of the same pair: all host cores
+    (row-parallel, legal for smoothFactor 1) and ONE core, which is what the reference itself uses."""
+    from oracle import oracle
+    cores = host_cores()
+    half = (bs - 1) // 2
+    rows = (half, min(height - half, half + cpu_rows))
+    t0 = time.perf_counter()
+    oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=rows, threads=cores)
+    dt = time.perf_counter() - t0
+    rows1 = (half, min(height - half, half + max(4, cpu_rows // 16)))
+    t0 = time.perf_counter()
+    oracle.block_left(left, right, bs, 0, max_d, cost=cost, rows=rows1, threads=1)
+    dt1 = time.perf_counter() - t0
+    return {
+        "value": round((rows[1] - rows[0]) * width * max_d / dt / 1e6, 2),
+        "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+        "sample": "rows [%d,%d) of the same pair (%.0f%% of it), oracle/ws_oracle.c row-parallel "
+                  "over %d threads, %.1f s" % (rows[0], rows[1], 100.0 * (rows[1] - rows[0]) / height, cores, dt),
+        "single_thread": {
+            "value": round((rows1[1] - rows1[0]) * width * max_d / dt1 / 1e6, 2), "unit": "Mdisparities/s",
+            "cores": 1, "sample": "rows [%d,%d) of the same pair, one thread (the reference is single-threaded, "
+                                  "BlockSearch.cpp:36-84), %.1f s" % (rows1[0], rows1[1], dt1)}}
 
 
 if __name__ == "__main__":

@@ -183,3 +183,123 @@ def block_left_smooth_py(L, R, block_size, max_disparity, smooth, cost="ssd"):
                     best, best_cx = dist, cx
             out[y, x] = float(x - best_cx)
     return out
+
+
+# ---- second witnesses for the branches ws_oracle.c had alone: right-view smoothFactor, LinearSearch
+# ---- smoothFactor, varBlock.  Literal raster-order loops on NumPy windows (tiny images only).
+def centred_norm_f32(win):
+    """cv::mean + cv::subtract(window, mean, s) + cv::norm(s, NORM_L2) on a CV_8UC3 window
+    (BlockSearch.cpp:125-129), as OpenCV 4.x evaluates them (un-vendored: restated).
+      mean     : per-channel double, exact integer sum / pixel count;
+      subtract : u8 Mat minus a non-integer Scalar works in FLOAT32 -- the Scalar is narrowed to float,
+                 the pixel widened to float, the difference rounded half-to-even and saturated to u8
+                 (arithm_op: depth2 = CV_32F for a u8 source, wtype = CV_32F; cvt32f8u = cvRound);
+                 an all-integer mean takes the u8 saturating path, which gives the same bytes;
+      norm     : sqrt of the exact integer sum of squares."""
+    if win.shape[0] == 0 or win.shape[1] == 0:
+        return 0.0
+    n = win.shape[0] * win.shape[1]
+    mean = win.reshape(-1, 3).astype(np.int64).sum(axis=0).astype(np.float64) / np.float64(n)
+    diff = win.astype(np.float32) - mean.astype(np.float32)[None, None, :]
+    s = np.clip(np.rint(diff), 0, 255).astype(np.int64)
+    return float(np.sqrt(np.float64((s * s).sum())))
+
+
+def centred_norm_f64(win):
+    """The same with the subtraction in float64 -- NOT what OpenCV does; kept to show where the two part."""
+    if win.shape[0] == 0 or win.shape[1] == 0:
+        return 0.0
+    n = win.shape[0] * win.shape[1]
+    mean = win.reshape(-1, 3).astype(np.int64).sum(axis=0).astype(np.float64) / np.float64(n)
+    s = np.clip(np.rint(win.astype(np.float64) - mean[None, None, :]), 0, 255).astype(np.int64)
+    return float(np.sqrt(np.float64((s * s).sum())))
+
+
+def _norm(a, b, cost):
+    d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+    return float(d.sum()) if cost == "sad" else float(np.sqrt(np.float64((d * d).sum())))
+
+
+def block_right_py(L, R, block_size, min_disparity, max_disparity, smooth=1.0, cost="ssd",
+                   var_block=False, thres=19.0, max_growth=1 << 20, only=None, texture=None):
+    """computeDisparityMapRight (BlockSearch.cpp:88-179) with smoothFactor and varBlock, literally.
+    Returns (map, max block size).  Raises ValueError where the reference would throw.
+    only = (y, x): just that pixel (smoothFactor 1 only); texture: the varBlock norm (default: float32)."""
+    texture = texture or centred_norm_f32
+    h1, w1 = L.shape[:2]
+    h2, w2 = R.shape[:2]
+    height = min(h1, h2)
+    out = np.zeros((h2, w2), dtype=np.float64)
+    max_block = block_size
+    fmax = np.finfo(np.float64).max
+    for y in range(height):
+        for x in range(w2):
+            if only is not None and (y, x) != tuple(only):
+                continue
+            if not R[y, x].any():
+                continue
+            bs = block_size
+
+            def clip(b):
+                hb = (b - 1) // 2
+                return min(x, hb), min(w2 - x - 1, hb), min(y, hb), min(h2 - y - 1, hb)
+
+            left, right, up, down = clip(bs)
+            if var_block:
+                for _ in range(max_growth):
+                    if not texture(R[y - up:y + down, x - left:x + right]) < thres:
+                        break
+                    grown = clip(bs + 4)
+                    bs += 4
+                    if grown == (left, right, up, down):
+                        break       # the reference would spin forever: growth is capped where nothing changes
+                    left, right, up, down = grown
+            max_block = max(max_block, bs)
+            rw = R[y - up:y + down, x - left:x + right]
+            area = (left + right) * (up + down)
+            best, best_cx = fmax, 0
+            for cx in range(x + min_disparity, x + max_disparity):
+                if cx + right >= w1:
+                    break
+                if cx - left < 0 or y + down > h1:
+                    raise ValueError("reference would throw (left ROI outside the image)")
+                lw = L[y - up:y + down, cx - left:cx + right]
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    dist = np.float64(_norm(lw, rw, cost)) / np.float64(area)      # 0/0 -> NaN never wins
+                    if y >= 1 and out[y - 1, x] == float(x - cx):
+                        dist = dist * np.float64(smooth)
+                    if x >= 1 and out[y, x - 1] == float(x - cx):
+                        dist = dist * np.float64(smooth)
+                if dist < best:
+                    best, best_cx = dist, cx
+            out[y, x] = float(best_cx - x)
+    return out, max_block
+
+
+def linear_py(L, R, smooth=1.0, search_range=200):
+    """LinearSearch::computeDisparityMap (LinearSearch.cpp:10-59) with smoothFactor, literally; candidates
+    past the left row's end are skipped (the build's definition of the reference's out-of-bounds read)."""
+    h1, w1 = L.shape[:2]
+    h2, w2 = R.shape[:2]
+    out = np.zeros((h2, w2), dtype=np.float64)
+    fmax = np.finfo(np.float64).max
+    Li, Ri = L.astype(np.int64), R.astype(np.int64)
+    for i in range(min(h1, h2)):
+        for j in range(w2):
+            if j < w1 and not L[i, j].any():
+                continue
+            best, col = fmax, 0
+            for k in range(j, j + search_range):
+                if k >= w1:
+                    break
+                d = Ri[i, j] - Li[i, k]
+                with np.errstate(invalid="ignore"):
+                    dist = np.sqrt(np.float64((d * d).sum()))
+                    if i >= 1 and out[i - 1, j] == float(j - k):
+                        dist = dist * np.float64(smooth)
+                    if j >= 1 and out[i, j - 1] == float(j - k):
+                        dist = dist * np.float64(smooth)
+                if dist < best:
+                    best, col = dist, k
+            out[i, j] = float(col - j)
+    return out

@@ -12,6 +12,7 @@ The functions mirror the reference's call surface:
 Images are H x W x 3 uint8 arrays (BGR), outputs float64 maps.
 """
 import ctypes
+import hashlib
 import os
 import subprocess
 
@@ -32,12 +33,46 @@ class _Image(ctypes.Structure):
                 ("height", ctypes.c_int), ("stride", ctypes.c_int)]
 
 
+def _host_signature():
+    """What -march=native depends on: the CPU model and its feature flags."""
+    model, flags = "", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = " ".join(sorted(line.split(":", 1)[1].split()))
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return hashlib.sha256((model + "|" + flags).encode()).hexdigest()
+
+
 def build(force=False):
-    """Compile libws_oracle.so with the Makefile next to this file."""
-    src = os.path.join(_HERE, "ws_oracle.c")
-    if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libws_oracle.so"])
+    """Compile libws_oracle.so with the Makefile next to this file.  The library is built with
+    -march=native, so it is rebuilt when it is older than its sources OR was built on another CPU
+    (the .so travels to the GPU box with the tree; its build host's signature sits beside it)."""
+    src = [os.path.join(_HERE, "ws_oracle.c"), os.path.join(_HERE, "ws_oracle.h"), os.path.join(_HERE, "Makefile")]
+    sig_path, sig = _LIB_PATH + ".host", _host_signature()
+    try:
+        built_on = open(sig_path).read().strip()
+    except OSError:
+        built_on = ""
+    lib_override = os.environ.get("WS_ORACLE_LIB")          # e.g. the sanitizer build (oracle/Makefile: asan)
+    if lib_override:
+        return lib_override
+    if (force or not os.path.exists(_LIB_PATH) or built_on != sig
+            or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(p) for p in src)):
+        tmp = "libws_oracle.so.tmp.%d" % os.getpid()       # aside + rename: no loader ever sees half a file
+        try:
+            subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "OUT=" + tmp, tmp])
+            os.replace(os.path.join(_HERE, tmp), _LIB_PATH)
+            with open(sig_path, "w") as f:
+                f.write(sig + "\n")
+        finally:
+            if os.path.exists(os.path.join(_HERE, tmp)):
+                os.remove(os.path.join(_HERE, tmp))
     return _LIB_PATH
 
 
@@ -58,6 +93,8 @@ def lib():
             ctypes.c_void_p, ctypes.c_int, P(ctypes.c_int)]
         _lib.wso_linear.argtypes = [P(_Image), P(_Image), ctypes.c_int, ctypes.c_double,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        _lib.wso_centred_norm.argtypes = [P(_Image)] + [ctypes.c_int] * 4
+        _lib.wso_centred_norm.restype = ctypes.c_double
         _lib.wso_evaldisp.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2 + [
             ctypes.c_float, ctypes.c_float, ctypes.c_int, P(ctypes.c_double)]
     return _lib
@@ -123,6 +160,14 @@ def linear(L, R, smooth=1.0, search_range=200, rows=None, threads=1):
     _check(lib().wso_linear(ctypes.byref(Li), ctypes.byref(Ri), search_range, smooth,
                             y0, y1, out.ctypes.data, out.shape[1]))
     return out
+
+
+def centred_norm(image, x0, y0, ww, wh):
+    """cv::norm(window - cv::mean(window), NORM_L2) of the varBlock texture test (BlockSearch.cpp:125-129)."""
+    a, im = _img(image)
+    if x0 < 0 or y0 < 0 or x0 + ww > a.shape[1] or y0 + wh > a.shape[0]:
+        raise ValueError("window outside the image")
+    return float(lib().wso_centred_norm(ctypes.byref(im), x0, y0, ww, wh))
 
 
 def evaldisp(disp, gt, mask, badthresh, maxdisp, rounddisp=0):

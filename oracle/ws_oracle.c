@@ -145,8 +145,19 @@ int wso_block_left(const wso_image *L, const wso_image *R, int block_size,
     return WSO_OK;
 }
 
-/* cv::mean + cv::subtract(window, mean) + cv::norm(.., NORM_L2) (BlockSearch.cpp:125-129). */
-static double centred_norm(const wso_image *im, int x0, int y0, int ww, int wh)
+/*
+ * cv::mean + cv::subtract(window, mean, s) + cv::norm(s, NORM_L2) (BlockSearch.cpp:125-129).
+ * OpenCV is un-vendored; restated from its 4.x behaviour: the mean is a per-channel double (exact
+ * integer sum / count); a CV_8U Mat minus a non-integer Scalar is evaluated in FLOAT32 (arithm_op
+ * narrows the Scalar to float and widens the pixel to float: depth2 = CV_32F, wtype = CV_32F) and
+ * converted back with saturate_cast<uchar>(cvRound(float)), round half to even; an all-integer
+ * mean takes the u8 saturating path, which gives the same bytes.  Float32 matters: with a mean
+ * whose fraction lies within half a float ulp of .5 -- only possible for windows of more than
+ * 32768 pixels, i.e. a varBlock window grown past ~182 x 182 on a near-flat region -- the float
+ * mean IS k + .5 and the tie rounds to even where a double subtraction would not tie at all
+ * (tests/test_oracle_construction.py shows such a window).
+ */
+double wso_centred_norm(const wso_image *im, int x0, int y0, int ww, int wh)
 {
     if (ww <= 0 || wh <= 0) return 0.0;
     double mean[3] = {0, 0, 0};
@@ -161,8 +172,10 @@ static double centred_norm(const wso_image *im, int x0, int y0, int ww, int wh)
         const uint8_t *p = px(im, y0 + r, x0);
         for (int i = 0; i < ww; ++i)
             for (int c = 0; c < 3; ++c) {
-                /* saturate_cast<uchar>(cvRound(p - mean)): round half to even, clamp */
-                double v = nearbyint((double)p[3 * i + c] - mean[c]);
+                /* saturate_cast<uchar>(cvRound((float)p - (float)mean)): round half to even, clamp */
+                volatile float fm = (float)mean[c];       /* (volatile: no double-precision shortcut) */
+                volatile float fd = (float)p[3 * i + c] - fm;
+                long v = lrintf(fd);
                 if (v < 0) v = 0;
                 if (v > 255) v = 255;
                 acc += (uint64_t)(v * v);
@@ -206,7 +219,7 @@ int wso_block_right(const wso_image *L, const wso_image *R, int block_size,
             int up = y < hb ? y : hb;                                /* :118 */
             int down = (h2 - y - 1) < hb ? (h2 - y - 1) : hb;        /* :119 */
             if (var_block) {                                         /* :129-142 */
-                while (centred_norm(R, x - left, y - up, left + right, up + down) < thres) {
+                while (wso_centred_norm(R, x - left, y - up, left + right, up + down) < thres) {
                     int pl = left, pr = right, pu = up, pd = down;
                     bs += 4;
                     hb = (bs - 1) / 2;

@@ -95,6 +95,12 @@ int wso_linear(const wso_image *L, const wso_image *R, int range, double smooth,
                int y0, int y1, double *out, int out_stride);
 
 /*
+ * The varBlock texture test alone: cv::norm(window - cv::mean(window), NORM_L2) of the ww x wh window at
+ * (x0, y0) (BlockSearch.cpp:125-129), with OpenCV's float32 subtraction (see ws_oracle.c).
+ */
+double wso_centred_norm(const wso_image *im, int x0, int y0, int ww, int wh);
+
+/*
  * evaldisp (utils.cpp:123-168): Middlebury bad-pixel statistics.
  * res[0]=n evaluated, res[1]=bad%, res[2]=invalid%, res[3]=total bad%,
  * res[4]=avgErr, res[5]=valid% of all pixels.

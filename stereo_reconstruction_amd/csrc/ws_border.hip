@@ -99,11 +99,14 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
         y0 = g.skip_y0 + seg * kRingTile;
         ny = min(kRingTile, g.skip_y1 - y0);
     }
+    // Rows y >= min(h1, h2) are never searched (BlockSearch.cpp:94,100): they stay 0, and their windows
+    // must not be staged either -- with h2 > h1 plane B (the left image) simply has no such rows.
+    const int nyc = min(ny, g.height - y0); // rows of this tile that are searched (uniform per workgroup)
     // canonical window columns under the tile (they fall as x rises) and window rows (they rise with y)
     const RingWin wfirst = ring_window(g, x0, y0), wlast = ring_window(g, x0 + nx - 1, y0);
     const int CA = min(wfirst.ca, wlast.ca), CE = max(wfirst.ce, wlast.ce);
     const int nc = min(max(CE - CA, 0), NCOLS);
-    const int RA = wfirst.ra, RE = max(ring_window(g, x0, y0 + ny - 1).re, RA);
+    const int RA = wfirst.ra, RE = nyc > 0 ? max(ring_window(g, x0, y0 + nyc - 1).re, RA) : RA;
     const int nr = min(RE - RA, NCOLS);
     // the strips of both planes under the tile's windows go through LDS: A once, B per round of 256
     // disparities (columns c - d + boff for c in [CA, CE), d in [dblk, dtop])
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
         sA[i] = g.A[(size_t)(RA + r) * g.pitch_a + (CA + c + g.pad_a)]; // (the windows lie inside the image)
     }
     if (tid < kRingTile * kRingTile) best[tid] = LLONG_MAX;
-    for (int dblk = g.d_lo; dblk <= g.d_hi; dblk += 256) {
+    for (int dblk = g.d_lo; dblk <= g.d_hi && nyc > 0; dblk += 256) {
         const int dtop = min(dblk + 255, g.d_hi);
         const int CB = CA - dtop + g.boff, WB = nc + (dtop - dblk);
         __syncthreads(); // (the previous round's readers are done with sB; first round: sA / best are written)
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
         // LDS reads are all in flight together -- the tile is latency-, not throughput-bound
         int32_t sum[NCOLS];
         int ra = 0, re = 0;
-        for (int j = 0; j < ny; ++j) {
+        for (int j = 0; j < nyc; ++j) {
             const int y = y0 + j;
             const RingWin wr = ring_window(g, x0, y); // (the window rows do not depend on x)
             const int r0 = wr.ra - RA, r1 = max(wr.re - RA, r0);
@@ -222,7 +225,7 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
     g.wa = c.wa; g.ha = c.ha; g.wb = c.wb;
     g.height = std::min(c.ha, c.hb);
     g.half = c.wh / 2; // right view: window (bs-1)^2 = (2*half)^2
-    g.boff = c.boff; g.d_lo = c.d_lo; g.d_hi = c.d_hi;
+    g.boff = c.boff; g.d_lo = c.d_lo; g.d_hi = c.d_hi_clipped;
     g.ssd = c.ssd; g.centred = march_centred(c);
     g.skip_x0 = skip.skip_x0; g.skip_x1 = skip.skip_x1; g.skip_y0 = skip.skip_y0; g.skip_y1 = skip.skip_y1;
     if (g.skip_x1 <= g.skip_x0 || g.skip_y1 <= g.skip_y0) { // no interior: every row is a "top" row
@@ -467,7 +470,8 @@ hipError_t launch_refine(const GenericArgs &g, hipStream_t s)
 // sums / min by shuffles.  Pixels whose window did not grow keep the ordinary search's result,
 // which is in the map already.
 // cv::mean / cv::subtract / cv::norm semantics (OpenCV 4.x restated; the library is
-// un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even(p - mean)), L2 norm.
+// un-vendored): double mean per channel, saturate_cast<uchar>(round-half-even((float)p - (float)mean))
+// -- the float32 path OpenCV takes for a u8 Mat minus a non-integer Scalar --, L2 norm.
 // Growth stops when the window no longer changes (the reference would loop forever there).
 // ------------------------------------------------------------------------------------------
 
@@ -498,13 +502,16 @@ __global__ void __launch_bounds__(256) ws_varblock_kernel(const GenericArgs g, d
                 const double area = (double)ww * (double)wh;
                 const double m0 = (double)wave_sum_u64(s0) / area, m1 = (double)wave_sum_u64(s1) / area,
                              m2 = (double)wave_sum_u64(s2) / area;
+                // cv::subtract(Mat_u8, Scalar) with a non-integer Scalar works in float32 (the Scalar narrowed to
+                // float, the pixel widened), then saturate_cast<uchar>(cvRound(.)), round half to even
+                const float f0 = (float)m0, f1 = (float)m1, f2 = (float)m2;
                 unsigned long long acc = 0;
                 for (int i = lane; i < n; i += 64) {
                     const uint8_t *p = w0 + (size_t)(i / ww) * g.s2 + 3 * (i % ww);
-                    const double v0 = fmin(255.0, fmax(0.0, rint((double)p[0] - m0)));
-                    const double v1 = fmin(255.0, fmax(0.0, rint((double)p[1] - m1)));
-                    const double v2 = fmin(255.0, fmax(0.0, rint((double)p[2] - m2)));
-                    acc += (unsigned long long)(v0 * v0) + (unsigned long long)(v1 * v1) + (unsigned long long)(v2 * v2);
+                    const int v0 = min(255, max(0, (int)rintf((float)p[0] - f0)));
+                    const int v1 = min(255, max(0, (int)rintf((float)p[1] - f1)));
+                    const int v2 = min(255, max(0, (int)rintf((float)p[2] - f2)));
+                    acc += (unsigned long long)(v0 * v0 + v1 * v1 + v2 * v2);
                 }
                 nrm = sqrt((double)wave_sum_u64(acc));
             }

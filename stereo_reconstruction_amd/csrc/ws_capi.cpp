@@ -45,6 +45,9 @@ struct ws_context {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+    hipEvent_t ev_scratch = nullptr;      // end of the last search: the scratch planes are free again
+    hipStream_t scratch_stream = nullptr; // ... the stream it ran on
+    bool scratch_busy = false;
     bool profiling = false, kernel_timed = false;
     DevBuf plane_a, plane_b, bias, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
     Job jobs[2];             // ws_enqueue_host alternates between two slots
@@ -147,11 +150,17 @@ int check_params(ws_context *ctx, const ws_params *p, const ws_image *L, const w
         if (p->min_disparity < 0)
             return fail(ctx, WS_ERR_GEOMETRY, "minDisparity < 0: left ROI starts before column 0 (BlockSearch.cpp:151)");
         // leftImage_(Rect(.., y-up, .., up+down)) needs y + down <= h1 (BlockSearch.cpp:151-154)
-        for (int y = 0; y < height; ++y) {
+        for (int y = std::max(0, height - half - 1); y < height; ++y) { // (only the last rows can overrun)
             const int down = std::min(h2 - y - 1, half);
             if (y + down > h1)
                 return fail(ctx, WS_ERR_GEOMETRY, "left image too short for the right view window at row %d", y);
         }
+        // varBlock grows windows by data: with a right image taller than the left one a grown window near
+        // row h1 needs left-image rows >= h1 and the reference throws (BlockSearch.cpp:151-154) -- but only
+        // if such a pixel happens to grow.  Defined here: rejected up front, whatever the data.
+        if (p->var_block && h2 > h1)
+            return fail(ctx, WS_ERR_GEOMETRY, "varBlock with a right image taller than the left one: a grown window "
+                                              "would leave the left image (BlockSearch.cpp:151-154)");
     }
     (void)w2;
     return WS_OK;
@@ -170,7 +179,9 @@ bool make_canon(const ws_params *p, const ws_image *L, const ws_image *R, Canon 
         k.ww = k.wh = p->block_size;
         k.wx0 = k.wy0 = -half;
         k.boff = 0;
-        k.d_lo = 1; k.d_hi = p->max_disparity;
+        // no candidate beyond what the geometry allows (x - d >= half with x <= w1 - 1 - half): a range far
+        // wider than the image costs neither d-group passes nor tie-tag bits; the tags keep their order
+        k.d_lo = 1; k.d_hi = k.d_hi_clipped = std::min(p->max_disparity, w1 - 1 - 2 * half);
         k.b_lo = half; k.b_hi = w2 - half - 1;
         k.ox0 = half; k.ox1 = w1 - half;
         k.oy0 = half; k.oy1 = height - half;
@@ -181,7 +192,9 @@ bool make_canon(const ws_params *p, const ws_image *L, const ws_image *R, Canon 
         k.ww = k.wh = 2 * half;
         k.wx0 = 1 - half; k.wy0 = -half;
         k.boff = w1 - w2;
-        k.d_lo = p->min_disparity; k.d_hi = p->max_disparity - 1;
+        // (x + d + half < w1 with x >= half: the same clamp)
+        k.d_lo = p->min_disparity; k.d_hi = std::min(p->max_disparity - 1, w1 - 1 - 2 * half);
+        k.d_hi_clipped = std::min(p->max_disparity - 1, w1 - 1); // border ring: x >= 0 and right >= 0 only
         k.b_lo = half; k.b_hi = w1 - 1 - half;
         k.ox0 = half; k.ox1 = w2 - half;
         k.oy0 = half; k.oy1 = std::min(h2 - half, height);
@@ -196,10 +209,31 @@ bool make_canon(const ws_params *p, const ws_image *L, const ws_image *R, Canon 
 int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
                float *out, int out_stride, hipStream_t s);
 
-// smoothFactor: for the right view and LinearSearch the factor can only reach d = 0 beside a
-// zero-valued neighbour (see ws_kernels.hip), and only when d = 0 is a candidate at all.
+int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
+                  float *out, int out_stride, hipStream_t s);
+
+// The context's scratch planes are shared by every call: a call on another stream than the previous
+// one first waits (on the device) for that previous call to be done with them.
 int run_device(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
                float *out, int out_stride, hipStream_t s)
+{
+    if (ctx->scratch_busy && s != ctx->scratch_stream) WS_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_scratch, 0));
+    const int rc = run_device_on(ctx, p, L, R, out, out_stride, s);
+    ctx->scratch_busy = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap == hipStreamCaptureStatusNone) { // (an event recorded inside a capture cannot be waited for outside it)
+        WS_HIP(ctx, hipEventRecord(ctx->ev_scratch, s));
+        ctx->scratch_busy = true;
+        ctx->scratch_stream = s;
+    }
+    return rc;
+}
+
+// smoothFactor: for the right view and LinearSearch the factor can only reach d = 0 beside a
+// zero-valued neighbour (see ws_smooth.hip), and only when d = 0 is a candidate at all.
+int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R,
+                  float *out, int out_stride, hipStream_t s)
 {
     ws_params q = *p;
     if (q.view == WS_VIEW_LINEAR) q.min_disparity = 0;
@@ -423,6 +457,7 @@ int ws_create(int device, ws_context **out)
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
         (e = hipEventCreate(&ctx->evk0)) != hipSuccess || (e = hipEventCreate(&ctx->evk1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_scratch, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->jobs[0].ev_h2d, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->jobs[0].ev_done, hipEventDisableTiming)) != hipSuccess ||
@@ -457,6 +492,7 @@ void ws_destroy(ws_context *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
+    if (ctx->ev_scratch) (void)hipEventDestroy(ctx->ev_scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1,5 +1,5 @@
 // ws_kernels.h -- launch interface between the C-ABI host code (ws_capi.cpp) and the
-// gfx950 kernels (ws_kernels.hip).  Internal; the public boundary is include/ws_stereo.h.
+// gfx950 kernels (ws_march / ws_prepass / ws_border / ws_smooth / ws_consumers .hip).  Internal; the public boundary is include/ws_stereo.h.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -21,7 +21,8 @@ struct Canon {
     int ww, wh;             // window width / height
     int wx0, wy0;           // window origin relative to the output pixel
     int boff;               // B column = x - d + boff
-    int d_lo, d_hi;         // inclusive candidate range
+    int d_lo, d_hi;         // inclusive candidate range (clamped to what complete windows allow)
+    int d_hi_clipped;       // ... and what the clipped windows of the right view's border ring allow
     int b_lo, b_hi;         // inclusive range of valid B centre columns
     int ox0, ox1, oy0, oy1; // outputs computed by the marching kernel: [ox0,ox1) x [oy0,oy1)
     int prefer_large;       // ties: 1 -> largest d wins (left), 0 -> smallest d (right)

@@ -26,9 +26,11 @@
 //                        same way (sliding box filter, exact in integers),
 //                      - the running minimum is a single signed v_min on (cost << k | tie tag),
 //                      - the d-chunks of a pixel meet through one ds_min_u64 per thread and row.
-//   ws_generic_kernel  literal per-pixel brute force: right-view border ring (clipped windows),
-//                    LinearSearch, and window sizes without a marching instantiation.
-//   ws_refine_kernel sub-pixel parabola (extension).
+//   ws_ring_kernel   right-view border ring (clipped windows): a small marching kernel, lanes over d.
+//   ws_linear_kernel LinearSearch through LDS.
+//   ws_generic_kernel  literal per-pixel brute force: window sizes without a marching instantiation
+//                    and LinearSearch ranges beyond 4096.
+//   ws_refine_*      sub-pixel parabola (extension).
 //
 // No MFMA: the hot loop is a stencil + reduction on bytes, bounded by VALU issue and LDS, see
 // DESIGN.md.  Wave64 throughout; nothing here assumes 32-wide warps.

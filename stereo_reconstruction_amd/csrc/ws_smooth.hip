@@ -20,6 +20,23 @@ namespace wsamd {
 constexpr uint8_t kSelFixed = 0x80; // value in the map is final; otherwise bits 0..2 = t_0..t_2
 constexpr uint8_t kSelZero = 0x40;  // with kSelFixed: that final value is 0
 
+// The three outcomes of a pixel, t_k = "the value is NOT 0 when k of its two neighbours hold 0", replaying
+// the reference's running minimum (BlockSearch.cpp:160-171, LinearSearch.cpp:39-49): d = 0 comes first with
+// dist0 = e0 * s (* s) -- successive multiplications -- and is accepted when dist0 < DBL_MAX, so an infinite
+// or NaN product (s = +-inf, 0 * inf, overflow) REFUSES d = 0; afterwards the best d >= 1 (distance e1,
+// no factor ever reaches it) replaces it when e1 < dist0.  Without any d >= 1 candidate (has_d1 false) the
+// refused d = 0 leaves minimumCorrespondX = 0, i.e. the fallback -x the d >= 1 search already stored.
+__device__ __forceinline__ uint8_t smooth_bits(double e0, double e1, bool has_d1, double s)
+{
+    uint8_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!(e0 < 1.7976931348623157e308) || (has_d1 && e1 < e0)) code |= (uint8_t)(1u << k);
+        e0 *= s;
+    }
+    return code;
+}
+
 __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArgs g, double s,
                                                                 uint8_t *__restrict__ sel, int sel_pitch)
 {
@@ -40,45 +57,35 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_kernel(const GenericArg
             const bool any = ww > 0 && wh > 0 && g.max_d > 0 && x + right < g.w1;
             if (!any) {
                 val = -(float)x; // no candidate at all: stores -x (BlockSearch.cpp:174)
-            } else if (!(g.max_d > 1 && x + 1 + right < g.w1)) {
-                val = 0.0f; // d = 0 is the only candidate
             } else {
+                // d = 0 may be the only candidate: then the d >= 1 search left its fallback -x in the map,
+                // which is also what the reference stores when d = 0 is refused (below)
+                const bool has_d1 = g.max_d > 1 && x + 1 + right < g.w1;
                 const uint8_t *rw = g.R + (size_t)(y - up) * g.s2 + 3 * (x - left);
-                const int d1 = (int)*o;
+                const int d1 = has_d1 ? (int)*o : 0;
                 const unsigned long long c0 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x - left), g.s1, rw, g.s2, ww, wh, g.ssd);
-                const unsigned long long c1 = window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd);
+                const unsigned long long c1 = has_d1 ? window_cost64(g.L + (size_t)(y - up) * g.s1 + 3 * (x + d1 - left), g.s1, rw, g.s2, ww, wh, g.ssd) : 0ull;
                 const double area = (double)(ww * wh);
                 const double e1 = (g.ssd ? sqrt((double)c1) : (double)c1) / area;
-                double e0 = (g.ssd ? sqrt((double)c0) : (double)c0) / area;
-                code = 0;
-                if (e1 < e0) code |= 1;
-                e0 *= s;
-                if (e1 < e0) code |= 2;
-                e0 *= s;
-                if (e1 < e0) code |= 4;
-                val = (float)d1;
+                const double e0 = (g.ssd ? sqrt((double)c0) : (double)c0) / area;
+                code = smooth_bits(e0, e1, has_d1, s);
+                val = has_d1 ? (float)d1 : -(float)x;
+                if (!has_d1 && x == 0) { code = kSelFixed; val = 0.0f; } // refused or not, column 0 stores 0 - 0
             }
         }
     } else { // LinearSearch: black test on the left pixel, distance of single pixels
         if (y < g.h1 && !(x < g.w1 && black3(g.L + (size_t)y * g.s1 + 3 * x))) {
             if (!(x < g.w1)) {
                 val = -(float)x;
-            } else if (!(g.linear_range > 1 && x + 1 < g.w1)) {
-                val = 0.0f;
             } else {
+                const bool has_d1 = g.linear_range > 1 && x + 1 < g.w1;
                 const uint8_t *pr = g.R + (size_t)y * g.s2 + 3 * x;
-                const int d1 = (int)*o;
+                const int d1 = has_d1 ? (int)*o : 0;
                 const uint32_t c0 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * x, 0, 1, 1, 1);
-                const uint32_t c1 = window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * (x + d1), 0, 1, 1, 1);
-                const double e1 = sqrt((double)c1);
-                double e0 = sqrt((double)c0);
-                code = 0;
-                if (e1 < e0) code |= 1;
-                e0 *= s;
-                if (e1 < e0) code |= 2;
-                e0 *= s;
-                if (e1 < e0) code |= 4;
-                val = (float)d1;
+                const uint32_t c1 = has_d1 ? window_cost(pr, 0, g.L + (size_t)y * g.s1 + 3 * (x + d1), 0, 1, 1, 1) : 0u;
+                code = smooth_bits(sqrt((double)c0), sqrt((double)c1), has_d1, s);
+                val = has_d1 ? (float)d1 : -(float)x;
+                if (!has_d1 && x == 0) { code = kSelFixed; val = 0.0f; } // refused or not, column 0 stores 0 - 0
             }
         }
     }
@@ -112,17 +119,11 @@ struct PreparePlanesArgs {
 
 // the three outcomes t_k = [c1 < c0 * s^k] with the reference's doubles
 template <bool SSD>
-__device__ __forceinline__ uint8_t smooth_code(long long c0, long long c1, double area, double s)
+__device__ __forceinline__ uint8_t smooth_code(long long c0, long long c1, bool has_d1, double area, double s)
 {
     const double e1 = (SSD ? sqrt((double)c1) : (double)c1) / area;
-    double e0 = (SSD ? sqrt((double)c0) : (double)c0) / area;
-    uint8_t code = 0;
-    if (e1 < e0) code |= 1;
-    e0 *= s;
-    if (e1 < e0) code |= 2;
-    e0 *= s;
-    if (e1 < e0) code |= 4;
-    return code;
+    const double e0 = (SSD ? sqrt((double)c0) : (double)c0) / area;
+    return smooth_bits(e0, e1, has_d1, s);
 }
 
 constexpr int kBoxRows = 32, kBoxMaxW = 16; // tile rows; widest / tallest right-view marching window
@@ -187,12 +188,13 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
         if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] != (CENTRED ? kCentre : 0u)) {
             if (!(g.d_hi >= 0 && xb0 >= g.b_lo)) {
                 val = -(float)xo; // no candidate at all
-            } else if (!(g.d_hi >= 1 && xb0 - 1 >= g.b_lo)) {
-                val = 0.0f; // d = 0 is the only candidate
             } else {
-                val = *o; // the search's d >= 1 winner stays unless the recurrence says 0
-                const long long c1 = (long long)g.cost[(size_t)y * g.cost_pitch + xo] + (SSD ? (long long)sa : 0LL);
-                code = smooth_code<SSD>((long long)c0, c1, area, g.s);
+                // the search's d >= 1 winner -- or, when d = 0 is the only candidate, its fallback -x --
+                // stays unless the recurrence says 0
+                const bool has_d1 = g.d_hi >= 1 && xb0 - 1 >= g.b_lo;
+                val = *o;
+                const long long c1 = has_d1 ? (long long)g.cost[(size_t)y * g.cost_pitch + xo] + (SSD ? (long long)sa : 0LL) : 0LL;
+                code = smooth_code<SSD>((long long)c0, c1, has_d1, area, g.s);
             }
         }
         *o = val;
@@ -229,9 +231,8 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
         const bool any = ww > 0 && wh > 0 && g.max_d > 0 && x + right < g.wb;
         if (!any) {
             val = -(float)x; // no candidate at all: stores -x (BlockSearch.cpp:174)
-        } else if (!(g.max_d > 1 && x + 1 + right < g.wb)) {
-            val = 0.0f; // d = 0 is the only candidate
         } else {
+            const bool has_d1 = g.max_d > 1 && x + 1 + right < g.wb; // else d = 0 is the only candidate
             const int ca = xm - right + 1; // first window column, canonical
             const uint32_t *pa0 = g.A + (size_t)(y - up) * g.pitch_a + ca + g.pad_a;
             const uint32_t *pb0 = g.B + (size_t)(y - up) * g.pitch_b + ca + g.boff + g.pad_b;
@@ -254,9 +255,10 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
             } else {
                 c0 = (long long)wave_sum_u64((unsigned long long)ab);
             }
-            val = *o;
-            const long long c1 = (long long)g.cost[(size_t)y * g.cost_pitch + x] + sa;
-            code = smooth_code<SSD>(c0, c1, (double)(ww * wh), g.s);
+            val = *o; // (without a d >= 1 candidate: the search's fallback -x)
+            const long long c1 = has_d1 ? (long long)g.cost[(size_t)y * g.cost_pitch + x] + sa : 0LL;
+            code = smooth_code<SSD>(c0, c1, has_d1, (double)(ww * wh), g.s);
+            if (!has_d1 && x == 0) { code = kSelFixed; val = 0.0f; } // refused or not, column 0 stores 0 - 0
         }
     }
     if (lane == 0) {

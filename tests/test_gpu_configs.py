@@ -1,0 +1,141 @@
+"""BASELINE.json configs that round 1 left without a device test: config 4 (the 15 trainingH shapes,
+batched and device-resident), config 5 WITH the sub-pixel refine at D = 1024 (two d-group passes
+meeting in the key plane before the parabola), and a MotorcycleE-shaped unequal pair at full size
+(results/Rectified/trainingH/MotorcycleE: 1481 x 1038 left, 1495 x 1052 right, SURVEY.md section 2
+row 15).  Full maps are checked through size-independent properties, oracle row bands bit for bit.
+"""
+import numpy as np
+import pytest
+
+from stereo_reconstruction_amd.synthetic import TRAINING_H, make_pair
+
+pytestmark = pytest.mark.gpu
+
+SUBPIXEL_TOL = 1e-4     # north_star: "within 1e-4 for float"
+
+
+def left_view_properties(got, gt, bs, maxd, w2=None):
+    """What holds for every left-view map of a synthetic pair (BlockSearch.cpp:24-86), any size."""
+    h, w = got.shape
+    half = (bs - 1) // 2
+    assert (got[:half] == 0).all() and (got[h - half:] == 0).all()
+    assert (got[:, :half] == 0).all() and (got[:, w - half:] == 0).all()
+    assert (got[half:h - half, half] == half).all()             # x = half: no candidate -> stores x
+    inner = got[half:h - half, half:w - half]
+    assert inner.min() >= 1 and inner.max() <= max(maxd, w) and (inner == np.round(inner)).all()
+    x_hi = w - half if w2 is None else min(w - half, w2 - half)
+    hit = (got[half:h - half, maxd:x_hi] == gt[half:h - half, maxd:x_hi]).mean() if x_hi > maxd else 1.0
+    assert hit > 0.6, hit
+
+
+def bands(h, half, n):
+    return [(half, half + n), (h // 2, h // 2 + n), (h - half - n, h - half)]
+
+
+@pytest.mark.parametrize("dmode", ["D256", "ndisp"])
+def test_config4_training_h_shapes(wslib, gpu_ctx, oracle, dmode):
+    """BASELINE.json configs[3]: 15 pairs with the trainingH shapes, 7x7 SSD, D = 256 and D = ndisp
+    (each scene's calib.txt), through the batched host entry points (ws_enqueue_host ... ws_wait) and
+    through ws_search_device; both must give the same bits, three oracle row bands per pair."""
+    import torch
+    bs = 7
+    half = 3
+    pairs, ds = [], []
+    for i, (_name, w, h, ndisp) in enumerate(TRAINING_H):
+        maxd = 256 if dmode == "D256" else ndisp
+        pairs.append(make_pair(w, h, maxd, 100 + i))
+        ds.append(maxd)
+    if dmode == "D256":
+        p = wslib.make_params(wslib.VIEW_LEFT, bs, 0, 256, 1.0, "ssd")
+        many = gpu_ctx.search_many(p, [(l, r) for l, r, _ in pairs], dtype=np.float32)
+    else:   # the range is a parameter of the call: one enqueue per pair with its own D, one wait
+        import ctypes
+        lib = wslib.load_library()
+        keep, many = [], []
+        for (l, r, _), maxd in zip(pairs, ds):
+            p = wslib.make_params(wslib.VIEW_LEFT, bs, 0, maxd, 1.0, "ssd")
+            La, Li = wslib._host_image(l)
+            Ra, Ri = wslib._host_image(r)
+            out = np.empty(La.shape[:2], dtype=np.float32)
+            assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri),
+                                       out.ctypes.data, out.shape[1], 0) == 0
+            keep.append((La, Ra, p))
+            many.append(out)
+        assert lib.ws_wait(gpu_ctx._h) == 0
+    for i, ((l, r, gt), maxd, got) in enumerate(zip(pairs, ds, many)):
+        name, w, h, _ = TRAINING_H[i]
+        assert got.shape == (h, w)
+        p = wslib.make_params(wslib.VIEW_LEFT, bs, 0, maxd, 1.0, "ssd")
+        tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        to = torch.empty((h, w), dtype=torch.float32, device="cuda")
+        gpu_ctx.search_device(p, tl, tr, to, None)
+        torch.cuda.synchronize()
+        assert "march" in gpu_ctx.last_launch()["kernel"], name
+        assert np.array_equal(to.cpu().numpy(), got), name
+        g64 = got.astype(np.float64)
+        for y0, y1 in bands(h, half, 2):
+            band = oracle.block_left(l, r, bs, 0, maxd, cost="ssd", rows=(y0, y1), threads=8)
+            assert np.array_equal(g64[y0:y1], band[y0:y1]), (name, maxd, y0)
+        left_view_properties(g64, gt, bs, maxd)
+
+
+def test_config5_subpixel_at_full_size(wslib, gpu_ctx, oracle):
+    """BASELINE.json configs[4]: 3840 x 2160, 9x9 SSD, D = 1024, parabolic refine.  D = 1024 runs as two
+    d-group passes whose keys meet in a plane (ws_march.hip) BEFORE the refine reads the winner: the
+    integer part must be the bit-exact argmin (BlockSearch.cpp:76-82), the fraction within 1e-4."""
+    w, h, bs, maxd = 3840, 2160, 9, 1024
+    half = 4
+    left, right, gt = make_pair(w, h, maxd, 5)
+    p = wslib.make_params(wslib.VIEW_LEFT, bs, 0, maxd, 1.0, "ssd")
+    assert wslib.plan(p, left.shape, right.shape)["passes"] >= 2
+    whole = wslib.BlockSearch(left, right, bs, 0, maxd, cost="ssd", context=gpu_ctx).computeDisparityMapLeft(1.0)
+    sub = wslib.BlockSearch(left, right, bs, 0, maxd, cost="ssd", subpixel=True, context=gpu_ctx).computeDisparityMapLeft(1.0)
+    assert "march" in gpu_ctx.last_launch()["kernel"]
+    left_view_properties(whole, gt, bs, maxd)
+    # the refine moves a disparity by at most half a step and never touches border / fallback pixels
+    frac = sub - whole
+    assert np.abs(frac).max() <= 0.5 + SUBPIXEL_TOL
+    assert (frac[:half] == 0).all() and (frac[:, :half] == 0).all() and (frac[half:h - half, half] == 0).all()
+    assert (frac != 0).mean() > 0.5         # and it does move most pixels
+    for y0, y1 in bands(h, half, 2):
+        want_int = oracle.block_left(left, right, bs, 0, maxd, cost="ssd", rows=(y0, y1), threads=8)
+        want_sub = oracle.block_left(left, right, bs, 0, maxd, cost="ssd", subpixel=True, rows=(y0, y1), threads=8)
+        assert np.array_equal(whole[y0:y1], want_int[y0:y1]), y0
+        err = np.abs(sub[y0:y1] - want_sub[y0:y1]).max()
+        assert err <= SUBPIXEL_TOL, (y0, err)
+        # integer part of the refined map == the argmin, recovered without the oracle's own fraction
+        assert np.array_equal(np.round(sub[y0:y1] - (want_sub[y0:y1] - want_int[y0:y1])), want_int[y0:y1]), y0
+
+
+def test_motorcycle_e_shaped_unequal_pair(wslib, gpu_ctx, oracle):
+    """Left 1481 x 1038, right 1495 x 1052 (the rectified MotorcycleE pair's shapes) with ~5 % black
+    border as the rectifying warp leaves it.  Left view in both orders; the right view is only legal
+    when the left image is at least as tall (BlockSearch.cpp:151-154 throws otherwise)."""
+    w1, h1, w2, h2, maxd = 1481, 1038, 1495, 1052, 140
+    left, right, gt = make_pair(w1, h1, maxd, 31, right_width=w2, right_height=h2)
+    left[:, :30] = 0
+    left[:12] = 0
+    right[:, w2 - 40:] = 0
+    right[h2 - 20:] = 0
+    half = 3
+    got = wslib.BlockSearch(left, right, 7, 0, maxd, cost="ssd", context=gpu_ctx).computeDisparityMapLeft(1.0)
+    assert "march" in gpu_ctx.last_launch()["kernel"]
+    assert got.shape == (h1, w1)
+    for y0, y1 in bands(h1, half, 2) + [(12, 14)]:
+        band = oracle.block_left(left, right, 7, 0, maxd, cost="ssd", rows=(y0, y1), threads=8)
+        assert np.array_equal(got[y0:y1], band[y0:y1]), y0
+    assert (got[:12] == 0).all() and (got[:, :30] == 0).all()      # black pixels are skipped
+    # the right view of this pair: the reference throws (left image too short for the bottom windows)
+    with pytest.raises(wslib.WsError) as e:
+        wslib.BlockSearch(left, right, 7, 0, maxd, context=gpu_ctx).computeDisparityMapRight(1.0)
+    assert e.value.code == -2
+    # swapped roles: taller / wider image on the left -> both views legal, map sizes differ
+    b = wslib.BlockSearch(right, left, 7, 0, maxd, cost="sad", context=gpu_ctx)
+    gl = b.computeDisparityMapLeft(1.0)
+    gr = b.computeDisparityMapRight(1.0)
+    assert gl.shape == (h2, w2) and gr.shape == (h1, w1)
+    assert (gl[h1 - half:] == 0).all()                              # rows >= min(h1,h2) - half stay 0
+    for y0, y1 in bands(h1, half, 2):
+        assert np.array_equal(gl[y0:y1], oracle.block_left(right, left, 7, 0, maxd, cost="sad", rows=(y0, y1), threads=8)[y0:y1])
+    for y0, y1 in [(0, 2), (h1 // 2, h1 // 2 + 2), (h1 - 2, h1)]:
+        assert np.array_equal(gr[y0:y1], oracle.block_right(right, left, 7, 0, maxd, cost="sad", rows=(y0, y1), threads=8)[y0:y1])

@@ -139,9 +139,13 @@ def test_subpixel_within_tolerance(wslib, gpu_ctx, oracle, view, cost):
     got = run(wslib, gpu_ctx, view, left, right, 9, 0, 64, cost, subpixel=True)
     want = ref(oracle, view, left, right, 9, 0, 64, cost, subpixel=True)
     assert np.abs(got - want).max() <= SUBPIXEL_TOL
-    # the integer part is still the bit-exact argmin
-    assert np.array_equal(np.round(got - (want - np.round(want))), np.round(want)) or \
-        np.abs(np.round(got) - np.round(want)).max() <= 1
+    # the integer part is still the bit-exact argmin: the refine adds a fraction in [-0.5, 0.5] to it
+    want_int = ref(oracle, view, left, right, 9, 0, 64, cost)
+    got_int = run(wslib, gpu_ctx, view, left, right, 9, 0, 64, cost)
+    assert np.array_equal(got_int, want_int)
+    assert np.abs(got - got_int).max() <= 0.5 + SUBPIXEL_TOL
+    assert np.array_equal(np.round(got - (want - want_int)), want_int)
+    assert ((got - got_int) != 0).mean() > 0.3
 
 
 @pytest.mark.parametrize("smooth", [0.9, 0.5, 1.7, 0.0])
@@ -169,7 +173,7 @@ def test_smooth_factor_right_view_and_linear(wslib, gpu_ctx, oracle, smooth, lev
 @pytest.mark.parametrize("levels", [256, 3, 2])
 def test_smooth_factor_left_view(wslib, gpu_ctx, oracle, smooth, levels):
     """Left view: the factor reaches whatever d the upper / left neighbour holds (BlockSearch.cpp:68-73),
-    a true raster-order dependency; the device iterates each row to its fixed point.  Factors outside
+    a true raster-order dependency; the device walks the anti-diagonals (ws_smooth.hip).  Factors outside
     [0,1] (a penalty, a sign flip) go through the three-best-candidates pass."""
     if levels == 256:
         left, right, _ = make_pair(300, 48, 40, seed=41)
@@ -606,3 +610,94 @@ def test_teddy_quarter_bad2_same_as_cpu(wslib, gpu_ctx, oracle):
     want = oracle.block_left(g["left"], g["right"], 5, 0, 64, cost="sad", threads=8)
     assert np.array_equal(got, want)
     assert wslib.evaldisp(got, g["gt"], g["mask"], 2.0, 64.0) == oracle.evaldisp(want, g["gt"], g["mask"], 2.0, 64.0)
+
+
+@pytest.mark.parametrize("case", [(3, 1, 1.0), (3, 80, 1.0), (4, 37, 0.9), (7, 1, 1.0), (7, 1, 0.9), (17, 1, 0.5), (2, 5, 1.0)])
+def test_right_view_with_a_taller_right_image(wslib, gpu_ctx, oracle, case):
+    """h2 > h1 is legal in the right view while no window needs a left-image row >= h1 (BlockSearch.cpp:151-154):
+    always for blockSize <= 4, and for h2 == h1 + 1.  Rows >= h1 of the map stay 0 (:94,:100); the border-ring
+    kernel must not stage windows there (plane B has no such rows)."""
+    bs, extra, smooth = case
+    h1 = 40
+    left, right, _ = make_pair(200, h1, 24, seed=60 + bs, right_width=190, right_height=h1 + extra)
+    right[h1 - 2:h1 + 1, 5:9] = 0
+    for cost in ("ssd", "sad"):
+        got = wslib.BlockSearch(left, right, bs, 0, 24, cost=cost, context=gpu_ctx).computeDisparityMapRight(smooth)
+        want = oracle.block_right(left, right, bs, 0, 24, smooth=smooth, cost=cost)
+        assert got.shape == (h1 + extra, 190)
+        assert np.array_equal(got, want), (bs, extra, cost)
+        assert (got[h1:] == 0).all()
+    with pytest.raises(wslib.WsError) as e:      # a grown window may need rows >= h1: defined as an error
+        wslib.BlockSearch(left, right, bs, 0, 24, context=gpu_ctx).computeDisparityMapRight(1.0, True, 30.0)
+    assert e.value.code == -2
+    if bs >= 7:                                   # two extra rows: the reference throws for the plain call too
+        _, r2, _ = make_pair(200, h1, 24, seed=61, right_width=190, right_height=h1 + 2)
+        with pytest.raises(wslib.WsError) as e:
+            wslib.BlockSearch(left, r2, bs, 0, 24, context=gpu_ctx).computeDisparityMapRight(1.0)
+        assert e.value.code == -2
+
+
+@pytest.mark.parametrize("smooth", [float("inf"), float("-inf"), 1e200, -1e200, 0.0])
+def test_non_finite_products_refuse_the_first_candidate(wslib, gpu_ctx, oracle, smooth):
+    """Right view / LinearSearch with a factor whose product with d = 0's distance is inf or NaN (0 * inf):
+    `dist < min` (BlockSearch.cpp:168, LinearSearch.cpp:46) is then false, d = 0 is REFUSED and the best d >= 1
+    -- or, without one, minimumCorrespondX = 0, i.e. -x -- is stored.  Images with exact matches at d = 0."""
+    rng = np.random.default_rng(12)
+    left = (rng.integers(0, 3, size=(36, 150, 3)) * 120).astype(np.uint8)
+    right = left[:, :140].copy()                       # d = 0 matches exactly: c0 = 0 everywhere
+    right[8:12, 30:60] = (rng.integers(0, 3, size=(4, 30, 3)) * 120).astype(np.uint8)
+    right[20, 70:75] = 0
+    for bs, cost, maxd in ((7, "ssd", 20), (5, "sad", 1), (3, "ssd", 12), (19, "ssd", 8)):
+        got = wslib.BlockSearch(left, right, bs, 0, maxd, cost=cost, context=gpu_ctx).computeDisparityMapRight(smooth)
+        want = oracle.block_right(left, right, bs, 0, maxd, smooth=smooth, cost=cost)
+        assert np.array_equal(got, want), (bs, cost, maxd)
+    for rng_ in (200, 1, 3):
+        got = wslib.LinearSearch(left, right, context=gpu_ctx, search_range=rng_).computeDisparityMap(smooth)
+        assert np.array_equal(got, oracle.linear(left, right, smooth=smooth, search_range=rng_)), rng_
+
+
+def test_range_far_wider_than_the_image_stays_on_the_marching_kernel(wslib, gpu_ctx, oracle):
+    """maxDisparity = 10 x width: the candidate range is clamped to what the geometry allows, so the search
+    needs one d-group pass and (SAD) no more tie-tag bits than the image is wide."""
+    left, right, _ = make_pair(300, 40, 64, seed=91)
+    for view, vid in (("left", wslib.VIEW_LEFT), ("right", wslib.VIEW_RIGHT)):
+        for cost in ("ssd", "sad"):
+            p = wslib.make_params(vid, 7, 0, 3000, 1.0, cost)
+            info = wslib.plan(p, left.shape, right.shape)
+            assert info["marching"] == 1 and info["passes"] == 1, (view, cost, info)
+            got = run(wslib, gpu_ctx, view, left, right, 7, 0, 3000, cost)
+            assert "march" in gpu_ctx.last_launch()["kernel"]
+            assert np.array_equal(got, ref(oracle, view, left, right, 7, 0, 3000, cost)), (view, cost)
+
+
+def test_calls_on_two_streams_share_the_scratch_safely(wslib, gpu_ctx, oracle):
+    """The context's scratch planes are shared by all calls: a call on another stream waits (on the device)
+    for the previous one.  Alternate two streams and two different pairs without any host sync."""
+    import torch
+    pairs = [make_pair(640, 200, 96, seed=s)[:2] for s in (101, 102)]
+    wants = [oracle.block_left(l, r, 7, 0, 96, threads=8) for l, r in pairs]
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
+    p = wslib.make_params(wslib.VIEW_LEFT, 7, 0, 96, 1.0, "ssd")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty((200, 640), dtype=torch.float32, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        gpu_ctx.search_device(p, dev[i & 1][0], dev[i & 1][1], o, streams[i & 1].cuda_stream)
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy().astype(np.float64), wants[i & 1]), i
+
+
+def test_var_block_texture_test_is_float32_like_opencv(wslib, gpu_ctx, oracle):
+    """cv::subtract(Mat_u8, Scalar) runs in float32.  Where the float mean is exactly k + .5 and the double
+    mean is not, the float subtraction ties (here: norm 0 < thres, the window grows once more to 263 x 263)
+    and a double one does not (norm 319, the window stays 261 x 261): different windows, different winners.
+    The device must follow the oracle (float32)."""
+    from test_oracle_construction import float32_tie_scene
+    left, right = float32_tie_scene()
+    got = wslib.BlockSearch(left, right, 3, 0, 32, context=gpu_ctx).computeDisparityMapRight(1.0, True, 10.0)
+    got_mb = gpu_ctx.last_max_block(3)
+    want, want_mb = oracle.block_right(left, right, 3, 0, 32, var_block=True, thres=10.0, rows=(129, 132), threads=8,
+                                       return_max_block=True)
+    assert np.array_equal(got[129:132], want[129:132])
+    assert got_mb >= want_mb >= 267

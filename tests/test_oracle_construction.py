@@ -156,3 +156,123 @@ def test_subpixel_is_exact_on_a_parabolic_cost(oracle):
     b = oracle.block_left(left, right, 5, 0, 16, subpixel=True)
     assert np.abs(a - b).max() <= 0.5 and (a != b).any()
     assert np.array_equal(np.round(b - (b - a)), a)
+
+
+# ---- second witnesses for the branches the C restatement had alone ---------------
+def few_levels(h, w, levels, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
+
+
+@pytest.mark.parametrize("smooth", [0.0, 0.9, 1.7, -0.5, float("inf")])
+@pytest.mark.parametrize("levels", [256, 3, 2])
+def test_right_view_smooth_factor_matches_literal_python(oracle, smooth, levels):
+    """Right view with smoothFactor (BlockSearch.cpp:160-165): tie-heavy images, minDisparity 0 and > 0,
+    clipped border windows, the -x fallback, exact d = 0 matches (0 * inf = NaN must refuse d = 0)."""
+    if levels == 256:
+        left, right = textured(11, 22, 40), textured(11, 20, 41)
+    else:
+        left, right = few_levels(11, 22, levels, 42), few_levels(11, 20, levels, 43)
+    right[2:6, 3:9] = left[2:6, 3:9]          # exact matches at d = 0
+    right[7, 5] = 0
+    for bs, mind, maxd, cost in ((5, 0, 6, "ssd"), (3, 0, 4, "sad"), (7, 2, 7, "ssd"), (2, 0, 3, "ssd"), (5, 0, 1, "sad")):
+        want, _ = brute.block_right_py(left, right, bs, mind, maxd, smooth, cost)
+        got = oracle.block_right(left, right, bs, mind, maxd, smooth=smooth, cost=cost)
+        assert np.array_equal(got, want), (bs, mind, maxd, cost)
+
+
+@pytest.mark.parametrize("smooth", [0.0, 0.9, 1.7, -0.5, float("inf")])
+def test_linear_search_smooth_factor_matches_literal_python(oracle, smooth):
+    """LinearSearch with smoothFactor (LinearSearch.cpp:39-44), few grey levels (ties, exact zeros)."""
+    for levels, seed in ((256, 50), (3, 51), (2, 52)):
+        left = textured(9, 26, seed) if levels == 256 else few_levels(9, 26, levels, seed)
+        right = textured(10, 24, seed + 100) if levels == 256 else few_levels(10, 24, levels, seed + 100)
+        right[3:5, 4:12] = left[3:5, 4:12]
+        left[6, 7] = 0
+        for rng_ in (1, 5, 200):
+            want = brute.linear_py(left, right, smooth, rng_)
+            assert np.array_equal(oracle.linear(left, right, smooth=smooth, search_range=rng_), want), (levels, rng_)
+
+
+@pytest.mark.parametrize("case", [(3, 40.0, "ssd", 0, 1.0), (5, 19.0, "ssd", 0, 0.9), (3, 150.0, "sad", 1, 1.0),
+                                  (7, 10.0, "ssd", 0, 1.7), (5, 1e9, "ssd", 0, 1.0)])
+def test_var_block_matches_literal_python(oracle, case):
+    """varBlock (BlockSearch.cpp:125-145): windows grow by 4 while the centred norm is below thres; the
+    search then uses the grown, re-clipped window; "max block size" (:177); thres = 1e9 grows every window
+    until it covers the image (the reference would spin forever; growth is capped where nothing changes)."""
+    bs, thres, cost, mind, smooth = case
+    left, right = textured(13, 24, 60), textured(13, 22, 61)
+    right[2:9, 4:14] = (right[2:9, 4:14] // 64) * 64       # weak texture
+    right[5:8, 15:20] = 90                                  # none
+    right[0, 0] = 0
+    want, want_mb = brute.block_right_py(left, right, bs, mind, 6, smooth, cost, var_block=True, thres=thres)
+    got, mb = oracle.block_right(left, right, bs, mind, 6, smooth=smooth, var_block=True, thres=thres, cost=cost,
+                                 return_max_block=True)
+    assert np.array_equal(got, want)
+    assert mb == want_mb and (mb > bs or thres < 20)
+
+
+def flat_window_where_float32_ties(side=261):
+    """side x side (odd count n > 65536), grey 200 with a centred block of (n - 1) / 2 pixels of 201:
+    mean = 200.5 - 1/(2n), less than half a float ulp (2^-17) below 200.5."""
+    n = side * side
+    assert n % 2 == 1 and 1.0 / (2 * n) < 2.0 ** -17
+    img = np.full((side, side), 200, dtype=np.uint8)
+    k = (n - 1) // 2
+    b = int(np.sqrt(k))                     # a centred b x b block of 201s, the rest of them in a ring row
+    lo = (side - b) // 2
+    img[lo:lo + b, lo:lo + b] = 201
+    rest = k - b * b
+    ring = [(lo - 1, x) for x in range(lo - 1, lo + b + 1)] + [(lo + b, x) for x in range(lo - 1, lo + b + 1)] + \
+           [(y, lo - 1) for y in range(lo, lo + b)] + [(y, lo + b) for y in range(lo, lo + b)]
+    for y, x in ring[:rest]:
+        img[y, x] = 201
+    assert int((img == 201).sum()) == k
+    return np.repeat(img[:, :, None], 3, axis=2)
+
+
+def test_centred_norm_is_the_float32_one(oracle):
+    """cv::subtract(Mat_u8, Scalar) with a non-integer Scalar runs in float32 (OpenCV 4.x arithm_op), not
+    double.  The two differ exactly when the float mean is k + .5 and the double mean is not -- the mean's
+    fraction within half a float ulp (2^-17 for means in [128, 256)) of .5 -- which needs more than 65536
+    pixels: a varBlock window grown past 256 x 256 on a near-flat region.  Such a window: 261 x 261, grey
+    200 with (n - 1) / 2 pixels of 201 -> mean = 200.5 - 1/(2n); as a float that IS 200.5, the 201s tie
+    (0.5 -> 0, half to even) and the norm is 0; in double 201 - mean > 0.5 rounds to 1."""
+    img = flat_window_where_float32_ties()
+    n = img.shape[0] * img.shape[1]
+    f32, f64 = brute.centred_norm_f32(img), brute.centred_norm_f64(img)
+    assert f32 == 0.0 and f64 == np.sqrt(3.0 * ((n - 1) // 2))
+    assert oracle.centred_norm(img, 0, 0, img.shape[1], img.shape[0]) == f32   # the oracle follows OpenCV's float32
+    # small windows (every window the tests and configs use without varBlock growth): no difference
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        win = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) if rng.random() < 0.5 else \
+            (rng.integers(0, 2, size=(h, w, 3)) + int(rng.integers(0, 255))).astype(np.uint8)
+        a = brute.centred_norm_f32(win)
+        assert a == brute.centred_norm_f64(win) == oracle.centred_norm(win, 0, 0, w, h)
+
+
+def float32_tie_scene():
+    """A right image in which pixel (130, 130) with blockSize 3 grows to the window [0,261) x [0,261) whose
+    mean is within half a float ulp of 200.5 (tests/test_oracle_construction.py); columns / rows from 261 on
+    are textured, so the NEXT window (blockSize 267) has a large norm."""
+    rng = np.random.default_rng(3)
+    right = rng.integers(1, 256, size=(280, 300, 3), dtype=np.uint8)
+    right[:261, :261] = flat_window_where_float32_ties(261)
+    left = rng.integers(1, 256, size=(280, 340, 3), dtype=np.uint8)
+    return left, right
+
+
+def test_float32_texture_test_changes_the_answer_where_it_ties(oracle):
+    """The deviation between OpenCV's float32 subtraction and a double one, end to end: pixel (130, 130) of
+    float32_tie_scene grows to 267 (float32: the 261 x 261 window's norm is 0) or stops at 263 (double: norm
+    319 >= thres), searches with different windows and finds different disparities.  The oracle is float32."""
+    left, right = float32_tie_scene()
+    a, mba = brute.block_right_py(left, right, 3, 0, 32, var_block=True, thres=10.0, only=(130, 130))
+    b, mbb = brute.block_right_py(left, right, 3, 0, 32, var_block=True, thres=10.0, only=(130, 130),
+                                  texture=brute.centred_norm_f64)
+    assert (mba, mbb) == (267, 263) and a[130, 130] != b[130, 130]
+    want, mb = oracle.block_right(left, right, 3, 0, 32, var_block=True, thres=10.0, rows=(130, 131), threads=8,
+                                  return_max_block=True)
+    assert want[130, 130] == a[130, 130] and mb >= 267
