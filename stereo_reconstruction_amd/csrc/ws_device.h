@@ -14,6 +14,7 @@ namespace wsamd {
 __host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int round_up_dev(int v, int m) { return (v + m - 1) / m * m; }
 
 // LDS regions of the target-image rows: a thread's run there starts at quad (X/4)*r + (ND/4)*k, so the
 // region of its m-th quad is only fixed at compile time if the region count divides both

@@ -51,6 +51,7 @@ struct MarchArgs {
     int nxr, nch;
     int wx0, wy0, boff;
     int d_lo, d_hi, b_lo, b_hi;
+    int d_top;     // d_lo + passes * chunks * ND - 1: the padded upper end of the range (SSD tie tags count from it)
     int d_first;   // first disparity of chunk 0 in THIS launch (d_lo + pass * chunks * ND)
     int pass_mode; // 0 = the only pass, 1 = first, 2 = middle, 3 = last of several d-group passes
     void *keys;    // several passes: plane of the best keys so far (slot_t per pixel)
@@ -93,24 +94,35 @@ __device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *base
 }
 
 // Asynchronous HBM -> LDS copy of one row (n dwords, 16-byte aligned source) into the region
-// layout, by the whole workgroup: global_load_lds_dwordx4, no VGPR staging.  The LDS address of
-// an LDS-DMA is wave-uniform base + lane * 16, so consecutive lanes fill consecutive quads of one
-// region and each lane fetches the quad that belongs there (the source address carries the
-// permutation).  Completion is covered by the vmcnt(0) hipcc places before the barrier.
+// layout: global_load_lds_dwordx4, no VGPR staging.  The LDS address of an LDS-DMA is wave-uniform
+// base (M0) + lane * 16, so consecutive lanes fill consecutive quads of one region and each lane
+// fetches the quad that belongs there (the source address carries the permutation).
+//
+// The instruction is issued through inline assembly ON PURPOSE: for the builtin the compiler makes
+// every later LDS read of the wave wait for vmcnt(0) (it cannot know the copy fills a ring slot nobody
+// reads in this step), which exposes the copy's whole latency at the top of the arithmetic; here
+// nothing waits until the explicit dma_wait() in front of the step's barrier (A/B on one MI355X,
+// config 2: 171 -> 166 us).  Dealing the copies of a step to different waves, with scalar addressing,
+// measured SLOWER (186-191 us): the loop below leaves them all to the workgroup's first wave.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int NREG>
-__device__ __forceinline__ void stage_row_async(uint32_t *row, int ro, const uint32_t *gsrc, int n,
-                                                int tid, int nt)
+__device__ __forceinline__ void stage_row_async(uint32_t *row, int ro, const uint32_t *gsrc, int n, int tid, int nt)
 {
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void glb_void;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const int lane = tid & 63;
     const int nquads = (n + 3) >> 2;
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
         const int nidx = (nquads - j + NREG - 1) / NREG; // quads of this region
-        for (int idx = tid; idx < nidx; idx += nt)
-            __builtin_amdgcn_global_load_lds((glb_void *)(gsrc + 4 * (idx * NREG + j)),
-                                             (lds_void *)(row + j * ro + 4 * (idx - lane)), 16, 0, 0);
+        for (int idx = tid; idx < nidx; idx += nt) {
+            // (M0 is written right in front of its use: nothing of the compiler's can sit between the two)
+            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)(row + j * ro + 4 * (idx - lane)));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :
+                         : "v"(gsrc + 4 * (idx * NREG + j)), "s"(la)
+                         : "memory");
+        }
     }
 }
 
@@ -121,24 +133,24 @@ __device__ __forceinline__ void stage_row_async(uint32_t *row, int ro, const uin
 //        (bias = box sum of the squared target pixels << LT, or poison for an invalid centre)
 // With KEY the candidate keys are folded into best[] (signed min; equal costs go to the smaller
 // tag, i.e. to the disparity the reference's strict '<' keeps).
-template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
-__device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X],
-                                          const uint32_t *runA, int ro_a, const uint32_t *runB,
-                                          int ro_b, const int32_t *runBias, int ro_bi, int shift)
+template <int X, int ND, int WW, bool SSD, bool KEY>
+__device__ __forceinline__ void march_load(uint32_t (&pa)[X + WW - 1], uint32_t (&pb)[X + WW + ND - 2], uint32_t (&bi)[X + ND - 1],
+                                           const uint32_t *runA, int ro_a, const uint32_t *runB, int ro_b,
+                                           const int32_t *runBias, int ro_bi)
 {
     constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
+    lds_run<X + WW - 1, NREG>(pa, runA, ro_a);
+    lds_run<X + WW + ND - 2, NREGB>(pb, runB, ro_b);
+    if constexpr (KEY && SSD) lds_run<X + ND - 1, NREGB>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
+}
+
+template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
+__device__ __forceinline__ void march_compute(int32_t (&V)[X][ND], int32_t (&best)[X], const uint32_t (&pa)[X + WW - 1],
+                                              const uint32_t (&pb)[X + WW + ND - 2], const uint32_t (&bi)[X + ND - 1], int shift)
+{
     constexpr int NA = X + WW - 1;
-    constexpr int NB = NA + ND - 1;
-    constexpr int NBI = X + ND - 1;
     // SAD accumulates +cost, SSD accumulates -2*cross: flip the sign of the update for SSD
     constexpr bool ADD = ((SIGN > 0) != SSD);
-
-    uint32_t pa[NA], pb[NB];
-    lds_run<NA, NREG>(pa, runA, ro_a);
-    lds_run<NB, NREGB>(pb, runB, ro_b);
-    uint32_t bi[NBI];
-    if constexpr (KEY && SSD) lds_run<NBI, NREGB>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
-
     // two disparities at a time: two independent prefix chains interleave in the issue stream
     // (a v_dot4 needs a wait state before its result can feed the next v_dot4's accumulator)
 #pragma unroll
@@ -168,6 +180,16 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
     }
 }
 
+template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
+__device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X],
+                                          const uint32_t *runA, int ro_a, const uint32_t *runB,
+                                          int ro_b, const int32_t *runBias, int ro_bi, int shift)
+{
+    uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], bi[X + ND - 1];
+    march_load<X, ND, WW, SSD, KEY>(pa, pb, bi, runA, ro_a, runB, ro_b, runBias, ro_bi);
+    march_compute<X, ND, WW, SSD, CENTRED, SIGN, KEY>(V, best, pa, pb, bi, shift);
+}
+
 template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
@@ -176,8 +198,10 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     constexpr int LT = ilog2c(ND);
     constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
     constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
-    typedef typename std::conditional<SSD, unsigned long long, int32_t>::type slot_t;
-    const slot_t kEmpty = SSD ? (slot_t)~0ull : (slot_t)INT_MAX;
+    // merge slots: SSD (cost << LT | 7) : global tie tag as one signed 64-bit key, SAD the 32-bit key itself;
+    // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
+    typedef typename std::conditional<SSD, long long, int32_t>::type slot_t;
+    const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : (slot_t)INT_MAX;
 
     extern __shared__ uint4 ws_smem4[];
     uint32_t *smem = reinterpret_cast<uint32_t *>(ws_smem4);
@@ -218,8 +242,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int ib = 4 * (((X / 4) * r + (ND / 4) * (g.nch - 1 - (worker ? c : 0))) / NREGB);
     const int d0 = g.d_first + c * ND; // first disparity of this thread's chunk
     const int shift = SSD ? LT + 1 : g.tag_bits;
-    // global tie tag of local tag jt is ctag + jt (SSD merge)
-    const int ctag = g.prefer_large ? g.d_hi - d0 - (ND - 1) : d0 - g.d_lo;
+    // SSD merge: global tie tag = chunk tag | local tag (a multiple of ND, so one v_and_or builds it):
+    // the chunk's distance from the preferred end of the padded range [d_lo, d_top]
+    const int ctag = g.prefer_large ? g.d_top - d0 - (ND - 1) : d0 - g.d_lo;
 
     int32_t V[X][ND];
 #pragma unroll
@@ -250,6 +275,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     stage_row_async<NREGB>(ringB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
     if (SSD && WH == 1)
         stage_row_async<NREGB>(reinterpret_cast<uint32_t *>(biasr), ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
+    dma_wait();
     __syncthreads();
 
     int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
@@ -264,7 +290,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             const int y = ys + oi - 1;
             slot_t *sl = slots + ((oi - 1) & 1) * tx;
             const uint32_t *rowA = ringA + out_slot * a_w;
-            for (int k = tid; k < tx; k += NT) {
+            // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
+            const int k = tid - (NT - round_up_dev(tx, 64));
+            if (k >= 0 && k < tx) {
                 const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r]
                 slot_t key = sl[si];
                 sl[si] = kEmpty;
@@ -274,26 +302,24 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     // meet in a plane of keys (same keys, same ordering: min is the merge)
                     slot_t *kp = static_cast<slot_t *>(g.keys) + (size_t)y * g.keys_pitch + x;
                     if (g.pass_mode != 1) key = min(key, *kp);
-                    if (g.pass_mode != 3) {
-                        *kp = key;
-                        continue;
-                    }
+                    if (g.pass_mode != 3) *kp = key;
                 }
-                if (x < g.ox1) {
+                if (x < g.ox1 && (g.pass_mode == 0 || g.pass_mode == 3)) {
                     const int xo = g.mirror ? g.wa - 1 - x : x;
                     float val;
-                    if (key == kEmpty) {
+                    const bool none = SSD ? (int32_t)((long long)key >> 32) >= kValidKeyBound : (int32_t)key >= kValidKeyBound;
+                    if (none) {
                         val = g.fallback_neg ? -(float)xo : (float)xo;
                     } else {
                         const int gtag = SSD ? (int)(uint32_t)key : ((int)key & ((1 << g.tag_bits) - 1));
-                        val = (float)(g.prefer_large ? g.d_hi - gtag : g.d_lo + gtag);
+                        val = (float)(g.prefer_large ? (SSD ? g.d_top : g.d_hi) - gtag : g.d_lo + gtag);
                     }
                     // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
                     if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
                     g.out[(size_t)y * g.out_pitch + xo] = val;
-                    if (COST && key != kEmpty) { // (a template flag: the test alone cost the hot kernel 2.7 %)
+                    if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
                         int32_t cst;
-                        if constexpr (SSD) cst = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+                        if constexpr (SSD) cst = (int32_t)((long long)key >> 32) >> LT;
                         else cst = (int32_t)key >> g.tag_bits;
                         g.cost_out[(size_t)y * g.cost_pitch + xo] = cst;
                     }
@@ -329,16 +355,13 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 #pragma unroll
                 for (int x = 0; x < X; ++x) {
                     const int32_t bk = best[x];
+                    // no validity test here: a poisoned key is just a large one, the flush sorts it out
                     if constexpr (SSD) {
-                        const int32_t t = bk >> LT;
-                        if (t < (kValidKeyBound >> LT)) {
-                            const uint32_t gtag = (uint32_t)(ctag + (bk & (ND - 1)));
-                            const unsigned long long key =
-                                ((unsigned long long)((uint32_t)t ^ 0x80000000u) << 32) | gtag;
-                            atomicMin(sl + x * g.nxr, key); // ds_min_u64, lanes on consecutive slots
-                        }
+                        const uint32_t gtag = (uint32_t)(bk & (ND - 1)) | (uint32_t)ctag; // v_and_or_b32
+                        const long long key = (long long)(((unsigned long long)(uint32_t)(bk | (ND - 1)) << 32) | gtag);
+                        atomicMin(sl + x * g.nxr, key); // ds_min_i64, lanes on consecutive slots
                     } else {
-                        if (bk < kValidKeyBound) atomicMin(sl + x * g.nxr, bk); // ds_min_i32
+                        atomicMin(sl + x * g.nxr, bk); // ds_min_i32
                     }
                 }
             } else {
@@ -347,7 +370,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             }
         }
 
-        __syncthreads(); // also waits for the asynchronous row copies (vmcnt(0))
+        dma_wait(); // the row copies issued at the top of this step have long landed
+        __syncthreads();
         add_slot = nxt_slot;
         if (++sub_slot == NR) sub_slot = 0;
         if (++out_slot == NR) out_slot = 0;
@@ -465,14 +489,18 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     if (tune_strip_rows > 0) {
         strips = ceil_div(out_h, tune_strip_rows);
     } else {
-        // one workgroup per CU; fill the chip once if the strips stay reasonably tall,
-        // otherwise aim at ~64-row strips in whole multiples of the CU count
-        strips = num_cus / m.tiles;
-        if (strips < 1) strips = 1;
-        if (ceil_div(out_h, strips) > 96) {
-            const int rounds = ceil_div(ceil_div(out_h, 64) * m.tiles, num_cus);
-            strips = rounds * num_cus / m.tiles;
-            if (strips < 1) strips = 1;
+        // One workgroup per CU at a time (its registers fill the CU).  A strip of R rows costs about
+        // R + (wh - 1) / 2 + 3 row times (the wh - 1 warm-up rows only add, the prologue is worth ~3 rows) and the
+        // chip works through ceil(workgroups / CUs) rounds of them: take the strip count with the cheapest total
+        // (config 3's own sweep, profiles/r01/sweep_tiles_config3.csv, has its minimum where this puts it).
+        double best_cost = 0.0;
+        strips = 1;
+        for (int sc = 1; sc <= out_h; ++sc) {
+            const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
+            if (st != sc) continue; // (the same strips as a smaller count already seen)
+            const int rounds = ceil_div(m.tiles * st, num_cus);
+            const double cost = rounds * (rows + 0.5 * (c.wh - 1) + 3.0);
+            if (sc == 1 || cost < best_cost) { best_cost = cost; strips = sc; }
         }
         if (strips > out_h) strips = out_h;
     }
@@ -550,6 +578,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.boff = c.boff;
     g.d_lo = c.d_lo;
     g.d_hi = c.d_hi;
+    g.d_top = c.d_lo + m.passes * m.nch * m.nd_per_thread - 1;
     g.b_lo = c.b_lo;
     g.b_hi = c.b_hi;
     g.tag_bits = tag_bits_for(c);

@@ -3,7 +3,7 @@
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$name -o run -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/$name.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$name -o run -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $R/gpurun_out/$name.log 2>&1
 python3 - <<PY
 import csv
 for r in csv.DictReader(open("$R/gpurun_out/$name/run_kernel_stats.csv")):

@@ -22,19 +22,19 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, int iters, uint32_t seed
             for (int c = 0; c < CHAINS; ++c) {
                 if (OP == 0) acc[c] = __builtin_amdgcn_sad_u8(a, b + c, acc[c]);
                 if (OP == 1) acc[c] = __builtin_amdgcn_udot4(a, b + c, acc[c], false);
-                if (OP == 2) acc[c] = (acc[c] << 3) + a;          // v_lshl_add_u32
+                if (OP == 2) acc[c] = (acc[c] << 3) + acc[(c + 1) % CHAINS];          // v_lshl_add_u32 (operands from the other chains: nothing folds)
                 if (OP == 3) acc[c] = min((int)acc[c], (int)(a + c)) + 1; // v_min + v_add
-                if (OP == 4) acc[c] = acc[c] - (b + c);           // v_sub
+                if (OP == 4) acc[c] = acc[c] - acc[(c + 1) % CHAINS];           // v_sub
                 if (OP == 5) acc[c] = __builtin_fmaf(__uint_as_float(acc[c]), 1.0001f, 0.5f); // v_fma_f32
-                if (OP == 6) acc[c] = (uint32_t)min(min((int)acc[c], (int)a), (int)(b + c)); // v_min3_i32
-                if (OP == 7) acc[c] = acc[c] + a + (b + c);       // v_add3_u32
+                if (OP == 6) acc[c] = (uint32_t)min(min((int)acc[c] + 0, (int)acc[(c + 1) % CHAINS] ^ (int)a), (int)acc[(c + 2) % CHAINS]); // v_xor + v_min3_i32
+                if (OP == 7) acc[c] = acc[c] + acc[(c + 1) % CHAINS] + acc[(c + 2) % CHAINS];       // v_add3_u32
                 if (OP == 8) acc[c] = (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)(b + c), (int)acc[c], false); // v_dot4_i32_i8
                 if (OP == 9) { // v_pk_add_u16
-                    u16x2 x = __builtin_bit_cast(u16x2, acc[c]), y = __builtin_bit_cast(u16x2, a);
+                    u16x2 x = __builtin_bit_cast(u16x2, acc[c]), y = __builtin_bit_cast(u16x2, acc[(c + 1) % CHAINS]);
                     acc[c] = __builtin_bit_cast(uint32_t, (u16x2)(x + y));
                 }
                 if (OP == 10) { // v_pk_min_u16
-                    u16x2 x = __builtin_bit_cast(u16x2, acc[c]), y = __builtin_bit_cast(u16x2, (uint32_t)(b + c));
+                    u16x2 x = __builtin_bit_cast(u16x2, acc[c] + 0x00010001u), y = __builtin_bit_cast(u16x2, acc[(c + 1) % CHAINS]);
                     acc[c] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
                 }
                 if (OP == 11) acc[c] = __builtin_amdgcn_perm(acc[c], a, 0x05040100u + c); // v_perm_b32
@@ -109,7 +109,7 @@ void run(const char *name, int waves_per_simd)
 {
     const int blocks = 256 * waves_per_simd; // 256-thread blocks = 4 waves = 1 per SIMD per block
     const float ms = time_ms([&](int iters) { hipLaunchKernelGGL((k<OP, CHAINS>), dim3(blocks), dim3(256), 0, 0, g_d, iters, 1u); });
-    const double insts_per_simd = 4000.0 * 16 * CHAINS * waves_per_simd * ((OP == 3 || OP == 13) ? 2 : 1);
+    const double insts_per_simd = 4000.0 * 16 * CHAINS * waves_per_simd * ((OP == 3 || OP == 13 || OP == 6 || OP == 10) ? 2 : 1);
     const double cyc = ms * 1e-3 * 2.4e9;
     printf("%-14s chains=%d waves/SIMD=%d : %8.3f ms -> %5.2f cycles(@2.4GHz)/wave-instr/SIMD, %6.2f Tlane-op/s\n", name, CHAINS,
            waves_per_simd, ms, cyc / insts_per_simd, insts_per_simd * 1024 * 64 / (ms * 1e-3) / 1e12);
@@ -140,10 +140,10 @@ int main()
         run<2, 4>("lshl_add", w);
         run<3, 4>("min+add", w);
         run<4, 4>("sub", w);
-        run<6, 4>("min3_i32", w);
+        run<6, 4>("xor+min3", w);
         run<7, 4>("add3", w);
         run<9, 4>("pk_add_u16", w);
-        run<10, 4>("pk_min_u16", w);
+        run<10, 4>("pk_add+pk_min", w);
         run<11, 4>("perm_b32", w);
         run<12, 4>("mad_u32_u24", w);
         run_mix<true>(w);

@@ -40,7 +40,7 @@ def run(workloads):
         for wl in workloads:
             env = dict(os.environ, WS_STEREO_LIB=os.path.join(VDIR, f))
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "20",
-                                "--warmup", "3", "--no-cpu-baseline", "--check"], env=env, capture_output=True, text=True)
+                                "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--check"], env=env, capture_output=True, text=True)
             try:
                 j = json.loads(r.stdout.strip().split("\n")[-1])
                 print("%-28s %-8s %10.0f Mdisp/s  step %.3f ms  kernel %.3f ms  check=%s" % (
