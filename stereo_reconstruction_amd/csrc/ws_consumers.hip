@@ -61,8 +61,161 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
+// ---- the box filter as prefix sums ---------------------------------------------------------
+// cv::blur sums a k x k window (k = 500 in the pipeline, main.cpp:53) around every pixel.  Here: per row an
+// inclusive prefix P of the row in double (LDS), the window sum of the REFLECT_101-extended row as a difference
+// of two prefix values -- the extension is periodic with period 2w - 2 and even, so the prefix F(t) of the
+// extended row is (t / T) * G(T) + G(t mod T) with G read off P -- then the same down the columns of the row
+// sums.  O(1) per pixel instead of O(k); every operation is a double addition / subtraction of sums that are
+// exact whenever the map's values are (integer-valued disparities: the pipeline reads an 8-bit PNG), so the
+// result is bit-identical to summing the window directly; for other inputs it is deterministic and differs
+// from a direct sum by double rounding only (OpenCV itself keeps running sums, in its own order).
+__device__ __forceinline__ double ext_prefix(const double *P, int n, long long t)
+{
+    // sum of the first t elements (t >= 0) of the periodic even extension of a line of n >= 2 elements,
+    // P[r] = sum of the line's first r elements
+    // (t < 2^31: the callers pass x0 + k <= n + k.  Windows shorter than the period -- the usual case, k = 500
+    // on images a few hundred pixels wide or more -- never divide.)
+    const uint32_t T = 2u * (uint32_t)n - 2u, ut = (uint32_t)t;
+    const uint32_t q = ut < T ? 0u : ut / T;
+    const int r = (int)(ut - q * T);
+    const double g = r <= n ? P[r] : P[n] + P[n - 1] - P[2 * n - 1 - r];
+    if (q == 0) return g;
+    return (double)q * (P[n] + P[n - 1] - P[1]) + g;
+}
+
+__device__ __forceinline__ double ext_window(const double *P, int n, int x0, int k)
+{
+    // sum of the k elements [x0, x0 + k) of the extended line (x0 may be negative, x0 + k > 0)
+    if (n == 1) return (double)k * P[1];
+    if (x0 >= 0) return ext_prefix(P, n, (long long)x0 + k) - ext_prefix(P, n, x0);
+    return (ext_prefix(P, n, (long long)(-x0) + 1) - P[1]) + ext_prefix(P, n, (long long)x0 + k);
+}
+
+// block-wide exclusive scan of one double per thread (256 threads), through LDS
+__device__ __forceinline__ double block_excl_scan_256(double v, double *wave_tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    double before = 0.0;
+    for (int i = 0; i < wv; ++i) before += wave_tot[i];
+    return before + (incl - v);
+}
+
+// one workgroup per row: prefix of the row in LDS, then the k-wide window sums (doubles) of the row
 __global__ void __launch_bounds__(256) ws_box_rows_kernel(const float *__restrict__ src, int sp, double *__restrict__ dst,
                                                           int dp, int w, int h, int k)
+{
+    extern __shared__ double box_lds[]; // P[0 .. w], 4 wave totals, then the row itself (floats, staged coalesced)
+    double *P = box_lds, *wave_tot = box_lds + (w + 1);
+    float *line = reinterpret_cast<float *>(wave_tot + 4);
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const float *row = src + (size_t)y * sp;
+    for (int i = tid; i < w; i += 256) line[i] = row[i];
+    __syncthreads();
+    const int per = (w + 255) / 256, i0 = tid * per, i1 = min(i0 + per, w);
+    double run = 0.0;
+    for (int i = i0; i < i1; ++i) run += (double)line[i];
+    const double offs = block_excl_scan_256(run, wave_tot);
+    run = offs;
+    if (tid == 0) P[0] = 0.0;
+    for (int i = i0; i < i1; ++i) {
+        run += (double)line[i];
+        P[i + 1] = run;
+    }
+    __syncthreads();
+    const int x00 = -(k / 2);
+    double *out = dst + (size_t)y * dp;
+    for (int x = tid; x < w; x += 256) out[x] = ext_window(P, w, x + x00, k);
+}
+
+// One workgroup per band of BW columns, all rows: thread (column c, chunk ch) keeps its chunk of the
+// column in registers, the chunk totals meet in LDS, the column's prefix C goes to LDS, then the k-tall
+// window sums, the scale and the reference's replacement rule (removeDisparityOutliers,
+// reconstruction.cpp:5-18: a pixel outside [thr_back, thr_front] x blurred takes the blurred value).
+constexpr int kColMaxPer = 32; // rows per thread at most
+
+template <int BW>
+__global__ void __launch_bounds__(1024) ws_outlier_cols_kernel(const double *__restrict__ rows, int rp, float *__restrict__ map,
+                                                                int mp, int w, int h, int k, float thr_front, float thr_back)
+{
+    extern __shared__ double box_lds[]; // C[(h + 1)][BW], then tot[NCH][BW]
+    constexpr int NCH = 1024 / BW;
+    double *C = box_lds, *tot = box_lds + (size_t)(h + 1) * BW;
+    const int c = threadIdx.x % BW, ch = threadIdx.x / BW;
+    const int x = blockIdx.x * BW + c;
+    const int L = (h + NCH - 1) / NCH;
+    const int ya = ch * L, yb = min(ya + L, h);
+    const bool live = x < w;
+    double v[kColMaxPer];
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < kColMaxPer; ++i) {
+        v[i] = 0.0;
+        if (live && ya + i < yb) v[i] = rows[(size_t)(ya + i) * rp + x];
+    }
+#pragma unroll
+    for (int i = 0; i < kColMaxPer; ++i) sum += v[i];
+    // exclusive scan of the chunk totals down the column: the lanes of a wave hold 64 / BW consecutive chunks of
+    // each column (lane = chunk-in-wave * BW + c), then the waves' totals meet in LDS
+    constexpr int CPW = 64 / BW; // chunks per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double incl = sum;
+#pragma unroll
+    for (int off = BW; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane >= 64 - BW) tot[wv * BW + c] = incl; // the wave's last chunk holds its column totals
+    __syncthreads();
+    double run = incl - sum;
+    for (int i = 0; i < wv; ++i) run += tot[i * BW + c];
+    (void)CPW;
+    if (ch == 0) C[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < kColMaxPer; ++i) {
+        if (ya + i < yb) {
+            run += v[i];
+            C[(size_t)(ya + i + 1) * BW + c] = run;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const double scale = 1.0 / ((double)k * (double)k);
+    for (int y = ya; y < yb; ++y) {
+        // the column's prefix sits at stride BW: gather the handful of values ext_window needs
+        const int y0 = y - k / 2;
+        double acc;
+        if (h == 1) {
+            acc = (double)k * C[BW + c];
+        } else {
+            auto Pc = [&](int r) { return C[(size_t)r * BW + c]; };
+            auto pre = [&](long long t) {
+                const uint32_t T = 2u * (uint32_t)h - 2u, ut = (uint32_t)t;
+                const uint32_t q = ut < T ? 0u : ut / T;
+                const int r = (int)(ut - q * T);
+                const double g = r <= h ? Pc(r) : Pc(h) + Pc(h - 1) - Pc(2 * h - 1 - r);
+                return q == 0u ? g : (double)q * (Pc(h) + Pc(h - 1) - Pc(1)) + g;
+            };
+            acc = y0 >= 0 ? pre((long long)y0 + k) - pre(y0) : (pre((long long)(-y0) + 1) - Pc(1)) + pre((long long)y0 + k);
+        }
+        const float blurred = (float)(acc * scale);
+        float *p = map + (size_t)y * mp + x;
+        const float d = *p;
+        if (d > __fmul_rn(thr_front, blurred) || d < __fmul_rn(thr_back, blurred)) *p = blurred;
+    }
+}
+
+// the literal O(k) form: lines too long for the LDS prefix (rows beyond 8190 pixels, columns beyond ~9500)
+__global__ void __launch_bounds__(256) ws_box_rows_direct_kernel(const float *__restrict__ src, int sp, double *__restrict__ dst,
+                                                                 int dp, int w, int h, int k)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -74,10 +227,8 @@ __global__ void __launch_bounds__(256) ws_box_rows_kernel(const float *__restric
     dst[(size_t)y * dp + x] = acc;
 }
 
-// column sums of the row sums, scale, and the reference's replacement rule
-// (removeDisparityOutliers, reconstruction.cpp:5-18)
-__global__ void __launch_bounds__(256) ws_outlier_kernel(const double *__restrict__ rows, int rp, float *__restrict__ map,
-                                                         int mp, int w, int h, int k, float thr_front, float thr_back)
+__global__ void __launch_bounds__(256) ws_outlier_direct_kernel(const double *__restrict__ rows, int rp, float *__restrict__ map,
+                                                                int mp, int w, int h, int k, float thr_front, float thr_back)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -94,11 +245,35 @@ __global__ void __launch_bounds__(256) ws_outlier_kernel(const double *__restric
 hipError_t launch_outliers(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, double *scratch,
                            hipStream_t s)
 {
-    dim3 grid(ceil_div(w, 256), h);
-    hipLaunchKernelGGL(ws_box_rows_kernel, grid, dim3(256), 0, s, map, mp, scratch, w, w, h, k);
+    constexpr size_t kLdsBudget = 150 * 1024;
+    // rows: one workgroup per row with the row's prefix in LDS
+    const size_t row_lds = (size_t)(w + 1 + 4) * sizeof(double) + (size_t)w * sizeof(float);
+    if (row_lds <= 64 * 1024) {
+        hipLaunchKernelGGL(ws_box_rows_kernel, dim3(h), dim3(256), row_lds, s, map, mp, scratch, w, w, h, k);
+    } else {
+        hipLaunchKernelGGL(ws_box_rows_direct_kernel, dim3(ceil_div(w, 256), h), dim3(256), 0, s, map, mp, scratch, w, w, h, k);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ws_outlier_kernel, grid, dim3(256), 0, s, scratch, w, map, mp, w, h, k, thr_front, thr_back);
+    // columns: the widest band whose column prefixes fit in LDS (and whose threads hold at most 32 rows each)
+    auto fits = [&](int bw) {
+        const int nch = 1024 / bw;
+        return (size_t)(h + 1 + nch) * bw * sizeof(double) <= kLdsBudget && ceil_div(h, nch) <= kColMaxPer;
+    };
+    auto launch = [&](auto kernel, int bw) -> hipError_t {
+        const size_t lds = (size_t)(h + 1 + 1024 / bw) * bw * sizeof(double);
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, bw)), dim3(1024), lds, s, scratch, w, map, mp, w, h, k, thr_front, thr_back);
+        return hipGetLastError();
+    };
+    // (narrower bands when the wide ones would leave most CUs without a workgroup)
+    if (fits(16) && ceil_div(w, 16) >= 200) return launch(ws_outlier_cols_kernel<16>, 16);
+    if (fits(8)) return launch(ws_outlier_cols_kernel<8>, 8);
+    if (fits(16)) return launch(ws_outlier_cols_kernel<16>, 16);
+    if (fits(4)) return launch(ws_outlier_cols_kernel<4>, 4);
+    if (fits(2)) return launch(ws_outlier_cols_kernel<2>, 2);
+    hipLaunchKernelGGL(ws_outlier_direct_kernel, dim3(ceil_div(w, 256), h), dim3(256), 0, s, scratch, w, map, mp, w, h, k, thr_front, thr_back);
     return hipGetLastError();
 }
 

@@ -1,0 +1,38 @@
+"""Developer tool (GPU box): the Reconstruction-side consumers (reconstruction.cpp:5-43, :152-196) on maps of
+the pipeline's sizes, checked against the NumPy restatement; run under `rocprofv3 --kernel-trace --stats` for the
+kernel durations (tools/consumers_prof.sh), which tools/consumers_report.py turns into HBM fractions."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import stereo_reconstruction_amd as ws  # noqa: E402
+from oracle import oracle  # noqa: E402
+from stereo_reconstruction_amd.synthetic import make_pair  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+ctx = ws.WindowSearch(0)
+for (w, h, d) in ((900, 750, 200), (1500, 1000, 256), (3840, 2160, 255)):
+    left, right, gt = make_pair(w, h, d, seed=3)
+    disp8 = np.clip(gt, 0, 255).astype(np.float32)
+    disp8[h // 3:h // 3 + 20, w // 4:w // 4 + 60] = 0
+    K = np.array([[3000, 0, w / 2], [0, 3000, h / 2], [0, 0, 1]], dtype=np.float32)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        filt = ctx.remove_disparity_outliers(disp8, 500, 1.5, 0.8)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        depth = ctx.convert_disparity_to_depth(filt, 3000.0, 1.0)
+    t2 = time.perf_counter()
+    for _ in range(reps):
+        pos, col = ctx.back_project(depth, K, right)
+    t3 = time.perf_counter()
+    ok = (np.array_equal(filt, oracle.remove_disparity_outliers(disp8, 500, 1.5, 0.8)) and
+          np.array_equal(depth, oracle.convert_disparity_to_depth(filt, 3000.0, 1.0)))
+    wp, wc = oracle.back_project(depth, K, right)
+    ok = ok and np.array_equal(pos, wp) and np.array_equal(col, wc)
+    print("%dx%d  host calls (incl. PCIe): outliers %.3f ms  depth %.3f ms  back-project %.3f ms  identical to the oracle: %s"
+          % (w, h, (t1 - t0) / reps * 1e3, (t2 - t1) / reps * 1e3, (t3 - t2) / reps * 1e3, ok), flush=True)
