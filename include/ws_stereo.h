@@ -207,6 +207,13 @@ int ws_last_launch_info(const ws_context *ctx, char *kernel_name, int name_cap,
                         int *threads, int *workgroups, int *lds_bytes);
 /* Tuning knob for the LDS tile sweep of BASELINE.json config 3: 0 = automatic. */
 int ws_set_tuning(ws_context *ctx, int x_runs_per_tile, int strip_rows, int threads);
+/*
+ * ws_search_host cuts a big call into row bands whose host<->device copies overlap the searches of their
+ * neighbours (smoothFactor 1, equal image heights; results are identical: each row only depends on the rows
+ * under its window, BlockSearch.cpp:46-66).  bands: -1 = automatic (4 for maps of a megapixel or more),
+ * 0 or 1 = never, 2..8 = that many.  For measurements; not part of the reference's surface.
+ */
+int ws_set_host_bands(ws_context *ctx, int bands);
 
 /* ---- Middlebury plumbing around the path ------------------------------------------ */
 /*

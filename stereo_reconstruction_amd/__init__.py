@@ -40,7 +40,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
-           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning",
+           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -139,6 +139,7 @@ def load_library(build_if_missing=False):
     lib.ws_last_max_block.argtypes = [vp, ci, P(ci)]
     lib.ws_last_launch_info.argtypes = [vp, ctypes.c_char_p, ci, P(ci), P(ci), P(ci)]
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
+    lib.ws_set_host_bands.argtypes = [vp, ci]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
     lib.ws_pfm_write.argtypes = [ctypes.c_char_p, vp, ci, ci, ci]
     lib.ws_ppm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_uint8)), P(ci), P(ci)]
@@ -200,11 +201,16 @@ class WindowSearch:
             raise WsError(rc, self._lib.ws_last_error(self._h).decode())
 
     # -- host buffers (numpy in, numpy out) ------------------------------------------------
-    def search(self, params, left, right, dtype=np.float64):
+    def search(self, params, left, right, dtype=np.float64, out=None):
+        """ws_search_host.  `out`: a C-contiguous float32 / float64 array of the map's shape to write into
+        (a caller that keeps its output buffer); by default a fresh array per call, as the reference returns."""
         La, Li = _host_image(left)
         Ra, Ri = _host_image(right)
         shape = La.shape[:2] if params.view == VIEW_LEFT else Ra.shape[:2]
-        out = np.empty(shape, dtype=dtype)
+        if out is None:
+            out = np.empty(shape, dtype=dtype)
+        elif out.shape != shape or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous array of shape %s" % (shape,))
         code = OUT_F64 if out.dtype == np.float64 else OUT_F32
         if out.dtype not in (np.float32, np.float64):
             raise ValueError("dtype must be float32 or float64")
@@ -298,6 +304,9 @@ class WindowSearch:
         v = ctypes.c_int()
         self._check(self._lib.ws_last_max_block(self._h, block_size, ctypes.byref(v)))
         return v.value
+
+    def set_host_bands(self, bands=-1):
+        self._check(self._lib.ws_set_host_bands(self._h, bands))
 
     def set_tuning(self, x_runs_per_tile=0, strip_rows=0, threads=0):
         self._check(self._lib.ws_set_tuning(self._h, x_runs_per_tile, strip_rows, threads))

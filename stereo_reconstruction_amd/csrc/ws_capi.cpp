@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,40 @@ struct Job { // one pair in flight on the batched host path
 
 thread_local std::string g_create_error; // ws_last_error(NULL): why the last ws_create on this thread failed
 
+// Caller buffers registered with the runtime for the duration of a banded boundary call: a copy from / to
+// pageable memory blocks the calling thread until it is done (measured: profiles/r02/pcie_probe.txt), so nothing
+// would overlap; registering costs microseconds on this platform.  One registry per process, reference counted
+// by (pointer, size): contexts on different threads may be handed the same images at the same time.
+struct PinnedRange { const void *p; size_t n; int refs; };
+std::mutex g_pin_mutex;
+std::vector<PinnedRange> g_pinned;
+
+bool pin_range(const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (PinnedRange &r : g_pinned)
+        if (r.p == p && r.n == n) { ++r.refs; return true; }
+    if (hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError(); // (registered by the caller already, overlapping another range, ...: copy unregistered)
+        return false;
+    }
+    g_pinned.push_back({p, n, 1});
+    return true;
+}
+
+void unpin_range(const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (size_t i = 0; i < g_pinned.size(); ++i)
+        if (g_pinned[i].p == p && g_pinned[i].n == n) {
+            if (--g_pinned[i].refs == 0) {
+                (void)hipHostUnregister(const_cast<void *>(p));
+                g_pinned.erase(g_pinned.begin() + (long)i);
+            }
+            return;
+        }
+}
+
 } // namespace
 
 struct ws_context {
@@ -53,6 +88,10 @@ struct ws_context {
     Job jobs[2];             // ws_enqueue_host alternates between two slots
     int job_next = 0;
     hipStream_t copy_stream = nullptr; // host <-> device copies of the batched path, beside the searches
+    hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
+    static constexpr int kMaxBands = 8;
+    hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
+    int host_bands = -1;               // ws_set_host_bands: 0 = never split, -1 = automatic
     std::string err;
     std::string last_kernel;
     int last_threads = 0, last_wgs = 0, last_lds = 0;
@@ -488,6 +527,14 @@ void ws_destroy(ws_context *ctx)
         if (j.ev_done) (void)hipEventDestroy(j.ev_done);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->down_stream) {
+        (void)hipStreamSynchronize(ctx->down_stream);
+        (void)hipStreamDestroy(ctx->down_stream);
+    }
+    for (int i = 0; i < ws_context::kMaxBands; ++i) {
+        if (ctx->ev_band_up[i]) (void)hipEventDestroy(ctx->ev_band_up[i]);
+        if (ctx->ev_band_done[i]) (void)hipEventDestroy(ctx->ev_band_done[i]);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
@@ -539,6 +586,93 @@ int ws_search_device(ws_context *ctx, const ws_params *p, const ws_image *left_d
     return run_device(ctx, p, left_dev, right_dev, out_dev, out_stride, s);
 }
 
+// One boundary call in row bands.  A pixel's result depends on the image rows its window covers and on nothing
+// else when smoothFactor == 1 (no raster dependency, no varBlock growth): the map's rows [y0, y1) are the interior
+// rows of a search on the sub-images [y0 - half, y1 + half).  So the call is cut into K bands and three queues run
+// beside each other: band k+1's image rows go up (copy_stream) while band k is searched (the context's stream) and
+// band k-1's map rows come down (down_stream) -- PCIe is full duplex and the copy engines are idle during a search.
+// The bytes that cross are the same as in the plain path; only their timing changes.  Results are identical
+// (tests/test_gpu_parity.py::test_host_call_in_bands_equals_the_plain_call).
+static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
+                              void *out, int out_dtype, int ow, int oh, int nb)
+{
+    const int half = (p->block_size - 1) / 2;
+    const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
+    const int H = oh; // (equal heights: the caller checked)
+    int rc;
+    if (!ctx->down_stream) WS_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+    for (int i = 0; i < nb; ++i) {
+        if (!ctx->ev_band_up[i]) WS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_band_up[i], hipEventDisableTiming));
+        if (!ctx->ev_band_done[i]) WS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_band_done[i], hipEventDisableTiming));
+    }
+    const size_t span_l = (size_t)left->stride * (H - 1) + lb, span_r = (size_t)right->stride * (H - 1) + rb;
+    if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_right, span_r)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * (H + 2 * half * nb) * 4)) != WS_OK) return rc;
+    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * H * 8)) != WS_OK) return rc;
+    const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+    uint8_t *dl = static_cast<uint8_t *>(ctx->d_left.p), *dr = static_cast<uint8_t *>(ctx->d_right.p);
+    float *scratch = static_cast<float *>(ctx->d_out.p);
+    const bool pin_l = pin_range(left->data, span_l), pin_r = pin_range(right->data, span_r);
+    const bool pin_o = pin_range(out, (size_t)ow * H * esz);
+    rc = [&]() -> int {
+    int up_to = 0; // image rows [0, up_to) are on their way up
+    for (int k = 0; k < nb; ++k) {
+        // the first band's upload and the last band's download are what nothing can hide: those two bands are
+        // half as tall as the others (nb >= 3)
+        auto cut = [&](int i) -> int {
+            if (nb < 3) return (int)((long long)H * i / nb);
+            const long long units = 2LL * nb - 2; // 1 + 2 (nb - 2) + 1 half-bands
+            const long long u = i == 0 ? 0 : i == nb ? units : 2LL * i - 1;
+            return (int)(H * u / units);
+        };
+        const int y0 = cut(k), y1 = cut(k + 1);
+        const int a = std::max(0, y0 - half), b = std::min(H, y1 + half);
+        if (b > up_to) { // the rows this band adds: one linear copy per image, row padding included
+            const size_t ol = (size_t)up_to * left->stride, orr = (size_t)up_to * right->stride;
+            const size_t nl = (size_t)(b - 1 - up_to) * left->stride + lb, nr = (size_t)(b - 1 - up_to) * right->stride + rb;
+            WS_HIP(ctx, hipMemcpyAsync(dl + ol, left->data + ol, nl, hipMemcpyHostToDevice, ctx->copy_stream));
+            WS_HIP(ctx, hipMemcpyAsync(dr + orr, right->data + orr, nr, hipMemcpyHostToDevice, ctx->copy_stream));
+            up_to = b;
+        }
+        WS_HIP(ctx, hipEventRecord(ctx->ev_band_up[k], ctx->copy_stream));
+        WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_band_up[k], 0));
+        ws_image bl{dl + (size_t)a * left->stride, left->width, b - a, left->stride};
+        ws_image br{dr + (size_t)a * right->stride, right->width, b - a, right->stride};
+        float *bout = scratch + (size_t)ow * (a + 2 * half * k); // the band's own map: its border rows are scrap
+        if ((rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream)) != WS_OK) return rc;
+        const float *valid = bout + (size_t)ow * (y0 - a);
+        const void *src = valid;
+        if (out_dtype == WS_OUT_F64) {
+            double *d64 = static_cast<double *>(ctx->d_out64.p) + (size_t)ow * y0;
+            WS_HIP(ctx, launch_widen(valid, ow, d64, ow, ow, y1 - y0, ctx->stream));
+            src = d64;
+        }
+        WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
+        WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
+        WS_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(out) + (size_t)ow * y0 * esz, src, (size_t)ow * (y1 - y0) * esz,
+                                   hipMemcpyDeviceToHost, ctx->down_stream));
+    }
+    return WS_OK;
+    }();
+    // (also after an error: nothing may still be copying when the ranges are released)
+    const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream),
+                     e3 = hipStreamSynchronize(ctx->down_stream);
+    if (pin_l) unpin_range(left->data, span_l);
+    if (pin_r) unpin_range(right->data, span_r);
+    if (pin_o) unpin_range(out, (size_t)ow * H * esz);
+    if (rc == WS_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+        return fail(ctx, WS_ERR_HIP, "banded host call: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
+    return rc;
+}
+
+int ws_set_host_bands(ws_context *ctx, int bands)
+{
+    if (!ctx || bands < -1 || bands > ws_context::kMaxBands) return WS_ERR_ARG;
+    ctx->host_bands = bands;
+    return WS_OK;
+}
+
 int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, const ws_image *right,
                    void *out, int out_stride, int out_dtype)
 {
@@ -551,6 +685,18 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     if (out_stride < ow) return fail(ctx, WS_ERR_ARG, "out_stride %d < width %d", out_stride, ow);
     WS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    {
+        // bands pay when the copies are worth hiding and each band still fills the chip
+        const bool can = (p->view == WS_VIEW_LEFT || p->view == WS_VIEW_RIGHT) && p->smooth_factor == 1.0 && !p->var_block &&
+                         left->height == right->height && out_stride == ow && linear_span(left) && linear_span(right) &&
+                         (size_t)left->stride <= 2 * (size_t)left->width * 3 && (size_t)right->stride <= 2 * (size_t)right->width * 3;
+        int nb = ctx->host_bands;
+        // (measured on one MI355X, tools/host_bands_time.py: 1.5 Mpixel 0.61 -> 0.47 ms with 2..4 bands,
+        // 5.9 Mpixel 2.6 -> 1.5 ms with 5..6; below a megapixel the bands' fixed costs eat the overlap)
+        const size_t px = (size_t)ow * oh;
+        if (nb < 0) nb = px < ((size_t)1 << 20) ? 0 : px < 3000000 ? 2 : px < 5000000 ? 4 : 6;
+        if (can && nb >= 2 && oh >= 64 * nb) return search_host_banded(ctx, p, left, right, out, out_dtype, ow, oh, nb);
+    }
     // One linear copy per image, row padding included (the kernels take any row stride): a 2-D copy
     // whose row length is not a multiple of 4 bytes -- 3 * width for most widths -- falls to a
     // per-row path in the runtime (measured: 15 ms instead of 0.2 ms for a 1482 x 994 image).

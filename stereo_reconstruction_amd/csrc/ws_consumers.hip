@@ -310,10 +310,36 @@ __global__ void __launch_bounds__(256) ws_depth_vertices_kernel(const float *__r
     }
 }
 
+// convertDisparityToDepth alone, four pixels per thread (16-byte loads and stores) for dense, aligned maps
+__global__ void __launch_bounds__(256) ws_depth4_kernel(const float4 *__restrict__ disp, float4 *__restrict__ depth, size_t n4,
+                                                        float focal, float baseline)
+{
+    const float minf = -INFINITY;
+    const float fb = __fmul_rn(focal, baseline);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 d = disp[i];
+        float4 z;
+        z.x = d.x == 0.0f ? minf : __fdiv_rn(fb, d.x);
+        z.y = d.y == 0.0f ? minf : __fdiv_rn(fb, d.y);
+        z.z = d.z == 0.0f ? minf : __fdiv_rn(fb, d.z);
+        z.w = d.w == 0.0f ? minf : __fdiv_rn(fb, d.w);
+        depth[i] = z;
+    }
+}
+
 hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float focal, float baseline, const float k[9],
                                  const uint8_t *bgr, int bstride, float *depth, int zp, float *pos, uint8_t *col,
                                  int input_is_depth, hipStream_t s)
 {
+    const size_t n = (size_t)w * h;
+    if (!pos && depth && !input_is_depth && dp == w && zp == w && (n & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(disp) | reinterpret_cast<uintptr_t>(depth)) & 15) == 0) {
+        const size_t n4 = n / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(ws_depth4_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(disp),
+                           reinterpret_cast<float4 *>(depth), n4, focal, baseline);
+        return hipGetLastError();
+    }
     dim3 grid(ceil_div(w, 256), h);
     hipLaunchKernelGGL(ws_depth_vertices_kernel, grid, dim3(256), 0, s, disp, dp, w, h, focal, baseline, k ? k[0] : 1.0f,
                        k ? k[4] : 1.0f, k ? k[2] : 0.0f, k ? k[5] : 0.0f, bgr, bstride, depth, zp,

@@ -701,3 +701,34 @@ def test_var_block_texture_test_is_float32_like_opencv(wslib, gpu_ctx, oracle):
                                        return_max_block=True)
     assert np.array_equal(got[129:132], want[129:132])
     assert got_mb >= want_mb >= 267
+
+
+@pytest.mark.parametrize("view", ["left", "right"])
+def test_host_call_in_bands_equals_the_plain_call(wslib, oracle, view):
+    """ws_search_host cuts big calls into row bands so that copies and searches overlap; a row's result only
+    depends on the rows under its window (BlockSearch.cpp:46-66, :120-158), so the maps must not change:
+    2..8 bands, odd sizes, both output types, sub-pixel, unequal widths -- and against the oracle."""
+    left, right, _ = make_pair(611, 263, 48, seed=95, right_width=590)
+    left[100:103, 50:90] = 0
+    right[200, 300:310] = 0
+    vid = wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT
+    with wslib.WindowSearch(0) as ctx:
+        for bs, cost, sub in ((7, "ssd", False), (9, "sad", True), (17, "ssd", False), (3, "sad", False)):
+            p = wslib.make_params(vid, bs, 0, 48, 1.0, cost, subpixel=sub)
+            ctx.set_host_bands(0)
+            plain64 = ctx.search(p, left, right, dtype=np.float64)
+            plain32 = ctx.search(p, left, right, dtype=np.float32)
+            for nb in (2, 3, 4, 8):
+                ctx.set_host_bands(nb)
+                assert np.array_equal(ctx.search(p, left, right, dtype=np.float64), plain64), (bs, cost, nb)
+                assert np.array_equal(ctx.search(p, left, right, dtype=np.float32), plain32), (bs, cost, nb)
+            if not sub:
+                f = oracle.block_left if view == "left" else oracle.block_right
+                assert np.array_equal(plain64, f(left, right, bs, 0, 48, cost=cost, threads=8))
+        # the automatic choice on a map of more than a megapixel
+        ctx.set_host_bands(-1)
+        big_l, big_r, _ = make_pair(1500, 1000, 64, seed=96)
+        p = wslib.make_params(vid, 7, 0, 64, 1.0, "ssd")
+        auto = ctx.search(p, big_l, big_r, dtype=np.float64)
+        ctx.set_host_bands(0)
+        assert np.array_equal(auto, ctx.search(p, big_l, big_r, dtype=np.float64))
