@@ -431,12 +431,12 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_wave_kernel(float *out, 
 //     untouched candidates in the reference's order (cost ascending, then d descending), kept per
 //     pixel by ws_left_top3_kernel.  For s >= 1 an unlisted neighbour value cannot win at all.
 // Pixel (y, x) needs (y-1, x) and (y, x-1): all pixels of an anti-diagonal x + y = k are
-// independent.  One workgroup, thread t = row, walks the diagonals (ws_smooth_left_wave_kernel):
-// the upper neighbour's value arrives through LDS from thread t-1 one step earlier, the left one is
-// the thread's own previous result, and the window distance of a neighbour's value is a SLIDING
-// sum along the row (the winner's cost at x-1 plus one window column entering, one leaving), so a
-// step costs O(bs) pixel operations, not O(bs^2).  No iteration, any image width; rows in bands
-// of 1024.
+// independent.  Bands of 64 rows, one wave each on its own CU, walk the diagonals
+// (ws_smooth_left_bands_kernel): the upper neighbour's value arrives from the lane above one step
+// earlier, the left one is the lane's own previous result, and the window distance of a neighbour's
+// value is a SLIDING sum (the cost at x-1 plus one window column entering, one leaving -- or the cost
+// at y-1 plus one row entering, one leaving), so a step costs O(bs) pixel operations, not O(bs^2).
+// No iteration, any image size.
 // ------------------------------------------------------------------------------------------
 struct SmoothLeftArgs {
     const uint8_t *L;
@@ -620,8 +620,6 @@ __global__ void __launch_bounds__(256) ws_left_cost_kernel(const SmoothLeftArgs 
     reinterpret_cast<uint2 *>(t)[2] = make_uint2(c[2], (uint32_t)dd[2]);
 }
 
-constexpr int kWaveRows = 1024; // rows per band = threads of the one workgroup
-
 // Sliding window sums.  The cost of (x, y, d) follows from the cost of (x-1, y, d) -- one window
 // column enters, one leaves -- or from the cost of (x, y-1, d) -- one window row enters, one leaves.
 // The raster pass is ONE workgroup whose step time is the latency of these sums, so on the planes
@@ -688,133 +686,177 @@ __device__ __forceinline__ uint32_t left_slide_down(const SmoothLeftArgs &g, uin
            window_cost(l0 + (size_t)(y - 1 - half) * g.s1, g.s1, r0 + (size_t)(y - 1 - half) * g.s2, g.s2, g.block_size, 1, g.ssd);
 }
 
-__global__ void __launch_bounds__(kWaveRows) ws_smooth_left_wave_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
-                                                                        int top_pitch)
+// The raster pass.  Rows are cut into bands of 64, one single-wave workgroup (on its own CU) per band, lane = row.
+// Lane t works on column k - t at step k, so the lanes of a wave sit on an anti-diagonal; the upper neighbour's
+// value and window cost are lane t-1's results of the previous step (one cross-lane move each, no LDS, no
+// barrier), the left ones are the lane's own.  Between bands the last row of band b hands every finished pixel to
+// the first row of band b+1 as ONE naturally aligned 8-byte word {value, cost} written with a device-scope store
+// and polled with device-scope loads (the word itself is the flag: it starts as all ones); band b+1 asks for a
+// column's word one step before it needs it, so in steady state -- every band runs the same program at the same
+// pace, 64 steps and a hand-off latency behind its predecessor -- the hand-off is off the critical path.
+// Band numbers are tickets drawn at start-up: a band's predecessor has then certainly started, whatever order
+// the workgroups are dispatched in.  A poll that never succeeds (it cannot, short of a bug) gives up after a
+// bounded number of tries and flags it instead of hanging the device.
+constexpr int kBandRows = 64;
+constexpr unsigned long long kEdgeNone = ~0ull;
+constexpr int kBandSpinLimit = 1 << 20;
+
+__global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
+                                                                         int top_pitch, unsigned long long *edge, int edge_pitch,
+                                                                         unsigned int *ctrl)
 {
-    __shared__ float vbuf[2][kWaveRows + 1];    // [step parity][row + 1]: the value a row produced in that step
-    __shared__ uint32_t cbuf[2][kWaveRows + 1]; // ... and that value's window cost there (kTopNone: not known)
     const int t = threadIdx.x;
+    unsigned int ticket = 0;
+    if (t == 0) ticket = atomicAdd(&ctrl[0], 1u);
+    const int band = (int)__builtin_amdgcn_readfirstlane(ticket);
     const int half = (g.block_size - 1) / 2;
     const int height = min(g.h1, g.h2);
     const int iw = g.w1 - 2 * half, ih = height - 2 * half; // interior
     const bool other_can_win = !(g.s >= 1.0); // (see above: for s >= 1 an unlisted neighbour value never wins)
     const bool slide_ok = g.block_size > 2;   // (a 1-pixel window is cheaper summed than slid)
-    for (int band = 0; band * kWaveRows < ih; ++band) {
-        const int y = half + band * kWaveRows + t;
-        const bool row_ok = y < height - half;
-        const int nrows = min(kWaveRows, ih - band * kWaveRows);
-        const int nsteps = iw + nrows - 1;
-        float *orow = g.out + (size_t)y * g.out_pitch;
-        const float *urow = g.out + (size_t)(y - 1) * g.out_pitch; // read by row 0 of the band only
-        const uint32_t *trow = top + (size_t)y * top_pitch * 6;
-        // the thread's running state along its row
-        float lv = 0.0f;          // value of (y, x-1); the ring column left of the interior holds 0
-        uint32_t lcost = 0;       // window cost of (x-1, lv) ...
-        bool lknown = false;      // ... if it is known
-        int uv = 0, ux = -2;      // last upper-neighbour value whose cost was needed, at column ux
-        uint32_t ucost = 0;
-        // entry of the pixel this thread handles next (prefetched one step ahead)
-        uint2 e0 = make_uint2(kTopNone, 0u), e1 = e0, e2 = e0;
-        float up0 = 0.0f;
-        if (row_ok && t == 0) {
-            const uint32_t *q = trow + (size_t)half * 6;
-            e0 = reinterpret_cast<const uint2 *>(q)[0]; e1 = reinterpret_cast<const uint2 *>(q)[1]; e2 = reinterpret_cast<const uint2 *>(q)[2];
-            if (y >= 1) up0 = urow[half];
+    const int y = half + band * kBandRows + t;
+    const bool row_ok = y < height - half;
+    const int nrows = min(kBandRows, ih - band * kBandRows);
+    if (nrows <= 0) return; // (uniform; the grid has exactly ceil(ih / 64) workgroups)
+    const int nsteps = iw + nrows - 1;
+    const unsigned long long *edge_in = edge + (size_t)band * edge_pitch; // written by the band above
+    unsigned long long *edge_out = edge + (size_t)(band + 1) * edge_pitch;
+    const bool hands_down = t == nrows - 1 && (band + 1) * kBandRows < ih;
+    float *orow = g.out + (size_t)y * g.out_pitch;
+    const uint32_t *trow = top + (size_t)y * top_pitch * 6;
+    // the lane's running state along its row
+    float lv = 0.0f;          // value of (y, x-1); the ring column left of the interior holds 0
+    uint32_t lcost = 0;       // window cost of (x-1, lv) ...
+    bool lknown = false;      // ... if it is known
+    int uv = 0, ux = -2;      // last upper-neighbour value whose cost was needed, at column ux
+    uint32_t ucost = 0;
+    float vprev = 0.0f;          // what this lane produced in the previous step (for the lane below)
+    uint32_t cprev = kTopNone;   // ... and that value's window cost there (kTopNone: not known)
+    // entry of the pixel this lane handles next (prefetched one step ahead)
+    uint2 e0 = make_uint2(kTopNone, 0u), e1 = e0, e2 = e0;
+    if (row_ok && t == 0) {
+        const uint32_t *q = trow + (size_t)half * 6;
+        e0 = reinterpret_cast<const uint2 *>(q)[0]; e1 = reinterpret_cast<const uint2 *>(q)[1]; e2 = reinterpret_cast<const uint2 *>(q)[2];
+    }
+    unsigned long long pre = kEdgeNone; // the band above's word for the column of the coming step
+    if (band > 0 && t == 0) pre = __hip_atomic_load(&edge_in[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool gave_up = false;
+    for (int k = 0; k < nsteps; ++k) {
+        const int xs = k - t;
+        const bool in = row_ok && xs >= 0 && xs < iw;
+        const int x = half + xs;
+        // prefetch the next pixel's entry
+        uint2 n0 = make_uint2(kTopNone, 0u), n1 = n0, n2 = n0;
+        if (row_ok && xs + 1 >= 0 && xs + 1 < iw) {
+            const uint32_t *q = trow + (size_t)(x + 1) * 6;
+            n0 = reinterpret_cast<const uint2 *>(q)[0]; n1 = reinterpret_cast<const uint2 *>(q)[1]; n2 = reinterpret_cast<const uint2 *>(q)[2];
         }
-        for (int k = 0; k < nsteps; ++k) {
-            const int xs = k - t;
-            const bool in = row_ok && xs >= 0 && xs < iw;
-            const int x = half + xs;
-            // prefetch the next pixel's entry (and, for the band's first row, its upper neighbour)
-            uint2 n0 = make_uint2(kTopNone, 0u), n1 = n0, n2 = n0;
-            float nup0 = 0.0f;
-            if (row_ok && xs + 1 >= 0 && xs + 1 < iw) {
-                const uint32_t *q = trow + (size_t)(x + 1) * 6;
-                n0 = reinterpret_cast<const uint2 *>(q)[0]; n1 = reinterpret_cast<const uint2 *>(q)[1]; n2 = reinterpret_cast<const uint2 *>(q)[2];
-                if (t == 0 && y >= 1) nup0 = urow[x + 1];
+        // the upper neighbour (y-1, x): the lane above finished it in the previous step
+        float upf = __shfl_up(vprev, 1, 64);
+        uint32_t c_above = __shfl_up(cprev, 1, 64);
+        if (t == 0) { upf = 0.0f; c_above = kTopNone; } // band 0: the ring row above the interior holds 0
+        if (band > 0) { // (uniform) lane 0's upper neighbour belongs to the band above
+            unsigned long long w = pre;
+            for (int spins = 0; !gave_up; ++spins) {
+                const bool wait = t == 0 && in && w == kEdgeNone;
+                if (!__builtin_amdgcn_ballot_w64(wait)) break;
+                if (spins > kBandSpinLimit) {
+                    gave_up = true;
+                    if (t == 0) atomicOr(&ctrl[1], 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                if (wait) w = __hip_atomic_load(&edge_in[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (in) {
-                const float upf = t == 0 ? up0 : vbuf[(k + 1) & 1][t];
-                const uint32_t c_above = t == 0 ? kTopNone : cbuf[(k + 1) & 1][t]; // cost of (x, y-1, up)
-                float v;
-                if (e0.x == kTopNone) {
-                    v = orow[x]; // black (0) or no candidate at all (x): fixed
-                    lknown = false;
-                } else {
-                    const int up = (int)upf;
-                    const bool up_ok = y >= 1 && (float)up == upf && left_candidate_ok(g, x, up, half);
-                    const int l = (int)lv;
-                    const bool l_ok = x >= 1 && (float)l == lv && left_candidate_ok(g, x, l, half);
-                    LeftBest b{1.7976931348623157e308, -1};
-                    uint32_t bcost = 0; // integer window cost of the running winner
-                    bool up_listed = false, l_listed = false;
-                    const uint2 es[3] = {e0, e1, e2};
+            if (t == 0 && in) {
+                upf = __uint_as_float((uint32_t)(w >> 32));
+                c_above = (uint32_t)w;
+                if (k + 1 < iw) pre = __hip_atomic_load(&edge_in[x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (in) {
+            float v;
+            if (e0.x == kTopNone) {
+                v = orow[x]; // black (0) or no candidate at all (x): fixed
+                lknown = false;
+            } else {
+                const int up = (int)upf;
+                const bool up_ok = y >= 1 && (float)up == upf && left_candidate_ok(g, x, up, half);
+                const int l = (int)lv;
+                const bool l_ok = x >= 1 && (float)l == lv && left_candidate_ok(g, x, l, half);
+                LeftBest b{1.7976931348623157e308, -1};
+                uint32_t bcost = 0; // integer window cost of the running winner
+                bool up_listed = false, l_listed = false;
+                const uint2 es[3] = {e0, e1, e2};
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (es[i].x == kTopNone) continue;
-                        const int d = (int)es[i].y;
-                        double m = left_dist_of(g, es[i].x);
-                        if (up_ok && up == d) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
-                        if (l_ok && l == d) { m *= g.s; l_listed = true; }    // the left factor second (:71-73)
-                        const int before = b.d;
-                        b.consider(m, d);
-                        if (b.d != before) bcost = es[i].x;
-                    }
-                    // the listed candidates' costs also serve the sliding sums below
-                    uint32_t cu = 0;
-                    bool cu_known = false;
-                    if (up_ok && !up_listed && other_can_win) {
-                        if (slide_ok && c_above != kTopNone) cu = left_slide_down(g, c_above, x, y, up, half);
-                        else if (slide_ok && ux == x - 1 && uv == up) cu = left_slide(g, ucost, x, y, up, half);
-                        else if (slide_ok && lknown && l == up && l_ok) cu = left_slide(g, lcost, x, y, up, half);
-                        else cu = left_cost_int(g, x, y, up, half);
-                        cu_known = true;
-                        double m = left_dist_of(g, cu) * g.s;
-                        if (l_ok && l == up) { m *= g.s; l_listed = true; }
-                        const int before = b.d;
-                        b.consider(m, up);
-                        if (b.d != before) bcost = cu;
-                    } else if (up_ok && !up_listed && l_ok && l == up) {
-                        l_listed = true; // (s >= 1: neither can win)
-                    }
-                    if (l_ok && !l_listed && other_can_win) {
-                        const uint32_t cl = slide_ok && lknown ? left_slide(g, lcost, x, y, l, half) : left_cost_int(g, x, y, l, half);
-                        const int before = b.d;
-                        b.consider(left_dist_of(g, cl) * g.s, l);
-                        if (b.d != before) bcost = cl;
-                    }
-                    // remember the upper value's cost for the next column
-                    if (up_ok) {
-                        if (cu_known) { uv = up; ucost = cu; ux = x; }
-                        else if (up_listed) {
+                for (int i = 0; i < 3; ++i) {
+                    if (es[i].x == kTopNone) continue;
+                    const int d = (int)es[i].y;
+                    double m = left_dist_of(g, es[i].x);
+                    if (up_ok && up == d) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
+                    if (l_ok && l == d) { m *= g.s; l_listed = true; }    // the left factor second (:71-73)
+                    const int before = b.d;
+                    b.consider(m, d);
+                    if (b.d != before) bcost = es[i].x;
+                }
+                // the listed candidates' costs also serve the sliding sums below
+                uint32_t cu = 0;
+                bool cu_known = false;
+                if (up_ok && !up_listed && other_can_win) {
+                    if (slide_ok && c_above != kTopNone) cu = left_slide_down(g, c_above, x, y, up, half);
+                    else if (slide_ok && ux == x - 1 && uv == up) cu = left_slide(g, ucost, x, y, up, half);
+                    else if (slide_ok && lknown && l == up && l_ok) cu = left_slide(g, lcost, x, y, up, half);
+                    else cu = left_cost_int(g, x, y, up, half);
+                    cu_known = true;
+                    double m = left_dist_of(g, cu) * g.s;
+                    if (l_ok && l == up) { m *= g.s; l_listed = true; }
+                    const int before = b.d;
+                    b.consider(m, up);
+                    if (b.d != before) bcost = cu;
+                } else if (up_ok && !up_listed && l_ok && l == up) {
+                    l_listed = true; // (s >= 1: neither can win)
+                }
+                if (l_ok && !l_listed && other_can_win) {
+                    const uint32_t cl = slide_ok && lknown ? left_slide(g, lcost, x, y, l, half) : left_cost_int(g, x, y, l, half);
+                    const int before = b.d;
+                    b.consider(left_dist_of(g, cl) * g.s, l);
+                    if (b.d != before) bcost = cl;
+                }
+                // remember the upper value's cost for the next column
+                if (up_ok) {
+                    if (cu_known) { uv = up; ucost = cu; ux = x; }
+                    else if (up_listed) {
 #pragma unroll
-                            for (int i = 0; i < 3; ++i)
-                                if (es[i].x != kTopNone && (int)es[i].y == up) { uv = up; ucost = es[i].x; ux = x; }
-                        }
-                    }
-                    if (b.d >= 0) {
-                        v = (float)b.d;
-                        lcost = bcost;
-                        lknown = true;
-                    } else {
-                        v = (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
-                        lknown = false;
+                        for (int i = 0; i < 3; ++i)
+                            if (es[i].x != kTopNone && (int)es[i].y == up) { uv = up; ucost = es[i].x; ux = x; }
                     }
                 }
-                orow[x] = v;
-                lv = v;
-                vbuf[k & 1][t + 1] = v;
-                cbuf[k & 1][t + 1] = lknown ? lcost : kTopNone;
+                if (b.d >= 0) {
+                    v = (float)b.d;
+                    lcost = bcost;
+                    lknown = true;
+                } else {
+                    v = (float)x; // nothing below DBL_MAX: minimumCorrespondX stays 0
+                    lknown = false;
+                }
             }
-            e0 = n0; e1 = n1; e2 = n2; up0 = nup0;
-            __syncthreads();
+            orow[x] = v;
+            lv = v;
+            vprev = v;
+            cprev = lknown ? lcost : kTopNone;
+            if (hands_down) // ONE 8-byte device-scope store: the band below polls this word
+                __hip_atomic_store(&edge_out[x], ((unsigned long long)__float_as_uint(v) << 32) | cprev, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
-        __threadfence(); // the next band's first row reads this band's last row from the map
-        __syncthreads();
+        e0 = n0; e1 = n1; e2 = n2;
     }
 }
 
-size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * 6 * sizeof(uint32_t); }
+// scratch of the raster pass behind the per-pixel candidate lists: 64 control bytes + one row of hand-off words per band
+static size_t smooth_left_edge_pitch(int w) { return (size_t)((w + 15) & ~15); }
+static size_t smooth_left_sync_bytes(int w, int h) { return 64 + ((size_t)h / kBandRows + 2) * smooth_left_edge_pitch(w) * 8; }
+
+size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * 6 * sizeof(uint32_t) + smooth_left_sync_bytes(w, h); }
 
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
                               hipStream_t st)
@@ -836,7 +878,15 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
         hipLaunchKernelGGL(ws_left_cost_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
     else
         hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
-    hipLaunchKernelGGL(ws_smooth_left_wave_kernel, dim3(1), dim3(kWaveRows), 0, st, a, top3, g.w1);
+    // hand-off words all ones ("not there yet"), ticket and error words zero
+    uint8_t *sync = reinterpret_cast<uint8_t *>(top3) + (size_t)g.w1 * g.h1 * 6 * sizeof(uint32_t);
+    const int nbands = ceil_div(ih, kBandRows);
+    const size_t pitch = smooth_left_edge_pitch(g.w1);
+    hipError_t e = hipMemsetAsync(sync + 64, 0xff, (size_t)(nbands + 1) * pitch * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(sync, 0, 64, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ws_smooth_left_bands_kernel, dim3(nbands), dim3(kBandRows), 0, st, a, top3, g.w1,
+                       reinterpret_cast<unsigned long long *>(sync + 64), (int)pitch, reinterpret_cast<unsigned int *>(sync));
     return hipGetLastError();
 }
 
