@@ -686,6 +686,69 @@ __device__ __forceinline__ uint32_t left_slide_down(const SmoothLeftArgs &g, uin
            window_cost(l0 + (size_t)(y - 1 - half) * g.s1, g.s1, r0 + (size_t)(y - 1 - half) * g.s2, g.s2, g.block_size, 1, g.ssd);
 }
 
+// ---- the two planes' moving windows in LDS -------------------------------------------------
+// A step of the raster pass is a chain of dependent loads (which neighbour value, then that value's window
+// line) with one wave per CU: its length is load latency.  So each band keeps the part of both dword planes
+// its diagonal can touch in LDS: rows [band's first row - half - 1, last row + half], and a circular window of
+// columns -- plane A the 2 half + 68 columns up to the diagonal's head, plane B max_d more to the left.
+// Column-major (a column's rows are contiguous, the lanes of a diagonal -- one row down, one column left each
+// -- fall on different banks because rp - 1 is odd).  Every step one new column per plane is requested two
+// steps ahead by LDS-DMA (global_load_lds_dword: lane = row, strided source, contiguous destination) and a
+// column that leaves the window is overwritten cw columns later.
+struct LeftLds {
+    uint32_t *A, *B;  // element (plane column c, plane row r) at [phys(c) * rp + (r - row0)]
+    int rp, cwa, cwb; // dwords per column, columns per window
+    int row0;         // plane row of LDS row 0
+    int wa, wb;       // a multiple of cwa / cwb not above the window's lowest column (so c - w < 2 cw)
+    __device__ __forceinline__ int pa(int c) const { const int p = c - wa; return p >= cwa ? p - cwa : p; }
+    __device__ __forceinline__ int pb(int c) const { const int p = c - wb; return p >= cwb ? p - cwb : p; }
+};
+
+template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
+__device__ __forceinline__ uint32_t left_pix_cost(uint32_t a, uint32_t b)
+{
+    if constexpr (MODE == 0) return pix_sad(a, b, 0u);
+    else return pix_dot<MODE == 2>(a, a, 0u) + pix_dot<MODE == 2>(b, b, 0u) - 2u * pix_dot<MODE == 2>(a, b, 0u); // (a-b)^2, exact in 32 bits
+}
+
+// n rows of column ca of plane A against column cb of plane B, from LDS row r on
+template <int MODE>
+__device__ __forceinline__ uint32_t lds_col_cost(const LeftLds &w, int ca, int cb, int r, int n)
+{
+    const uint32_t *pa = w.A + w.pa(ca) * w.rp + r, *pb = w.B + w.pb(cb) * w.rp + r;
+    uint32_t acc = 0;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) acc += left_pix_cost<MODE>(pa[i], pb[i]);
+    return acc;
+}
+
+// n columns from ca0 / cb0 on, LDS row r
+template <int MODE>
+__device__ __forceinline__ uint32_t lds_row_cost(const LeftLds &w, int ca0, int cb0, int r, int n)
+{
+    uint32_t acc = 0;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) acc += left_pix_cost<MODE>(w.A[w.pa(ca0 + i) * w.rp + r], w.B[w.pb(cb0 + i) * w.rp + r]);
+    return acc;
+}
+
+// one plane column into its LDS slot: lane = LDS row (two instructions for up to 128 rows), rows clamped to the plane
+__device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch, int plane_rows, int col, uint32_t *slot, int row0,
+                                                int rows, int lane)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const int c = min(max(col, 0), pitch - 1);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int r = part * 64 + lane;
+        if (r < rows) {
+            const uint32_t *src = plane + (size_t)min(max(row0 + r, 0), plane_rows - 1) * pitch + c;
+            const uint32_t dst = (uint32_t)(uintptr_t)(lds_u32 *)(slot + part * 64);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(dst) : "memory");
+        }
+    }
+}
+
 // The raster pass.  Rows are cut into bands of 64, one single-wave workgroup (on its own CU) per band, lane = row.
 // Lane t works on column k - t at step k, so the lanes of a wave sit on an anti-diagonal; the upper neighbour's
 // value and window cost are lane t-1's results of the previous step (one cross-lane move each, no LDS, no
@@ -701,10 +764,16 @@ constexpr int kBandRows = 64;
 constexpr unsigned long long kEdgeNone = ~0ull;
 constexpr int kBandSpinLimit = 1 << 20;
 
+constexpr int kBandDepth = 3; // steps a pixel's inputs (candidate list, map value, hand-off word) are requested ahead
+constexpr int kBandLag = 8;   // columns a band stays behind what its requests need from the band above
+constexpr int kBandFill = 5;  // steps a window column is requested ahead of its first use
+
+template <int MODE> // -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
 __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
                                                                          int top_pitch, unsigned long long *edge, int edge_pitch,
-                                                                         unsigned int *ctrl)
+                                                                         unsigned int *ctrl, int cwa, int cwb)
 {
+    extern __shared__ uint4 ws_smem4[];
     const int t = threadIdx.x;
     unsigned int ticket = 0;
     if (t == 0) ticket = atomicAdd(&ctrl[0], 1u);
@@ -722,8 +791,8 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     const unsigned long long *edge_in = edge + (size_t)band * edge_pitch; // written by the band above
     unsigned long long *edge_out = edge + (size_t)(band + 1) * edge_pitch;
     const bool hands_down = t == nrows - 1 && (band + 1) * kBandRows < ih;
-    float *orow = g.out + (size_t)y * g.out_pitch;
-    const uint32_t *trow = top + (size_t)y * top_pitch * 6;
+    float *orow = g.out + (size_t)min(y, height - 1) * g.out_pitch;
+    const uint32_t *trow = top + (size_t)min(y, height - 1) * top_pitch * 6;
     // the lane's running state along its row
     float lv = 0.0f;          // value of (y, x-1); the ring column left of the interior holds 0
     uint32_t lcost = 0;       // window cost of (x-1, lv) ...
@@ -732,32 +801,138 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     uint32_t ucost = 0;
     float vprev = 0.0f;          // what this lane produced in the previous step (for the lane below)
     uint32_t cprev = kTopNone;   // ... and that value's window cost there (kTopNone: not known)
-    // entry of the pixel this lane handles next (prefetched one step ahead)
-    uint2 e0 = make_uint2(kTopNone, 0u), e1 = e0, e2 = e0;
-    if (row_ok && t == 0) {
-        const uint32_t *q = trow + (size_t)half * 6;
-        e0 = reinterpret_cast<const uint2 *>(q)[0]; e1 = reinterpret_cast<const uint2 *>(q)[1]; e2 = reinterpret_cast<const uint2 *>(q)[2];
-    }
-    unsigned long long pre = kEdgeNone; // the band above's word for the column of the coming step
-    if (band > 0 && t == 0) pre = __hip_atomic_load(&edge_in[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool gave_up = false;
-    for (int k = 0; k < nsteps; ++k) {
-        const int xs = k - t;
-        const bool in = row_ok && xs >= 0 && xs < iw;
-        const int x = half + xs;
-        // prefetch the next pixel's entry
-        uint2 n0 = make_uint2(kTopNone, 0u), n1 = n0, n2 = n0;
-        if (row_ok && xs + 1 >= 0 && xs + 1 < iw) {
-            const uint32_t *q = trow + (size_t)(x + 1) * 6;
-            n0 = reinterpret_cast<const uint2 *>(q)[0]; n1 = reinterpret_cast<const uint2 *>(q)[1]; n2 = reinterpret_cast<const uint2 *>(q)[2];
+
+    // A band starts once the band above is kBandLag columns into its last row: from then on both run the same
+    // program at the same pace, and a hand-off word asked for kBandDepth steps early has been written by then.
+    if (band > 0) {
+        const int xl = half + min(kBandLag, iw - 1);
+        unsigned long long w = kEdgeNone;
+        for (int spins = 0;; ++spins) {
+            if (t == 0) w = __hip_atomic_load(&edge_in[xl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__builtin_amdgcn_ballot_w64(t == 0 && w == kEdgeNone)) break;
+            if (spins > kBandSpinLimit) {
+                gave_up = true;
+                if (t == 0) atomicOr(&ctrl[1], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
         }
+    }
+
+    // the LDS windows (MODE >= 0): image columns [0, 2 half + kBandFill) before the first step, then one per step
+    LeftLds win{};
+    const int lds_rows = kBandRows + 2 * half + 1;
+    if constexpr (MODE >= 0) {
+        win.rp = lds_rows + 1; // even
+        win.cwa = cwa; win.cwb = cwb;
+        win.A = reinterpret_cast<uint32_t *>(ws_smem4);
+        win.B = win.A + (size_t)cwa * win.rp;
+        win.row0 = band * kBandRows - 1; // = (the band's first row) - half - 1
+        win.wa = (g.pad_a / cwa) * cwa; win.wb = (g.pad_b / cwb) * cwb;
+        for (int c = 0; c < 2 * half + kBandFill; ++c) {
+            lds_fill_column(g.A, g.pitch_a, g.h1, c + g.pad_a, win.A + win.pa(c + g.pad_a) * win.rp, win.row0, lds_rows, t);
+            lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, t);
+        }
+    }
+    // window cost of candidate d at (x, y) from the cost at (x-1, y), from the cost at (x, y-1), or summed whole
+    auto cost_slide = [&](uint32_t c_prev, int x, int d) -> uint32_t {
+        if constexpr (MODE >= 0) {
+            const int r = y - half - win.row0;
+            return c_prev + lds_col_cost<MODE>(win, x + half + g.pad_a, x + half - d + g.pad_b, r, g.block_size) -
+                   lds_col_cost<MODE>(win, x - 1 - half + g.pad_a, x - 1 - half - d + g.pad_b, r, g.block_size);
+        } else {
+            return left_slide(g, c_prev, x, y, d, half);
+        }
+    };
+    auto cost_slide_down = [&](uint32_t c_up, int x, int d) -> uint32_t {
+        if constexpr (MODE >= 0) {
+            const int ca = x - half + g.pad_a, cb = x - half - d + g.pad_b;
+            return c_up + lds_row_cost<MODE>(win, ca, cb, y + half - win.row0, g.block_size) -
+                   lds_row_cost<MODE>(win, ca, cb, y - 1 - half - win.row0, g.block_size);
+        } else {
+            return left_slide_down(g, c_up, x, y, d, half);
+        }
+    };
+    auto cost_full = [&](int x, int d) -> uint32_t {
+        if constexpr (MODE >= 0) {
+            uint32_t acc = 0;
+            for (int i = 0; i < g.block_size; ++i)
+                acc += lds_col_cost<MODE>(win, x - half + i + g.pad_a, x - half + i - d + g.pad_b, y - half - win.row0, g.block_size);
+            return acc;
+        } else {
+            return left_cost_int(g, x, y, d, half);
+        }
+    };
+
+    // A step's result leaves at the top of the NEXT step (the map pixel, and for the band's last row the hand-off
+    // word: ONE 8-byte device-scope store the band below polls).
+    int store_x = -1;
+    auto flush_result = [&]() {
+        if (store_x >= 0) {
+            orow[store_x] = vprev;
+            if (hands_down)
+                __hip_atomic_store(&edge_out[store_x], ((unsigned long long)__float_as_uint(vprev) << 32) | cprev, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            store_x = -1;
+        }
+    };
+
+    // What a pixel starts from -- its candidate list, the map's value there (black / no candidate: fixed) and, for
+    // the band's first row, the hand-off word of the pixel above -- is requested kBandDepth steps before its
+    // step and queues up in registers: the step never waits for a load it issued itself.  (The window columns
+    // are requested BEFORE these loads in every step and waits retire in order, so a column asked for
+    // kBandFill > kBandDepth steps ahead has landed once the loads of the same step have been consumed.)
+    // The queue is kBandDepth register slots used round-robin by a loop unrolled kBandDepth times (no moves: a move
+    // would have to wait for the load it moves).
+    struct Slot { uint2 a0, a1, a2; float ao; unsigned long long aw; };
+    Slot slot[kBandDepth];
+#pragma unroll
+    for (int i = 0; i < kBandDepth; ++i) {
+        slot[i].a0 = slot[i].a1 = slot[i].a2 = make_uint2(kTopNone, 0u);
+        slot[i].ao = 0.0f;
+        slot[i].aw = kEdgeNone;
+    }
+    auto step = [&](const int k, Slot &sl) {
+        if (k >= nsteps) return; // (uniform)
+        const int xs = k - t;
+        const bool in = k >= 0 && row_ok && xs >= 0 && xs < iw;
+        const int x = half + xs;
+        flush_result();
+        if constexpr (MODE >= 0) {
+            if (k >= 0) {
+                // the windows' lowest columns are k - 64 and k - 64 - max_d (image columns)
+                const int lo_a = max(k - 64, 0) + g.pad_a, lo_b = max(k - 64 - g.max_d, 0) + g.pad_b;
+                if (lo_a >= win.wa + win.cwa) win.wa += win.cwa;
+                if (lo_b >= win.wb + win.cwb) win.wb += win.cwb;
+                const int cn = k + 2 * half + kBandFill; // first read at step k + kBandFill
+                lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, t);
+                lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, t);
+            }
+        }
+        // this step's inputs leave their slot, the inputs of step k + kBandDepth take it
+        const uint2 e0 = sl.a0, e1 = sl.a1, e2 = sl.a2;
+        const float omap = sl.ao;
+        unsigned long long w = sl.aw;
+        {
+            const int xn = xs + kBandDepth; // (clamped, not branched: every step issues the same loads)
+            const bool on = row_ok && xn >= 0 && xn < iw;
+            const int xc = half + min(max(xn, 0), iw - 1);
+            const uint32_t *q = trow + (size_t)xc * 6;
+            sl.a0 = on ? reinterpret_cast<const uint2 *>(q)[0] : make_uint2(kTopNone, 0u);
+            sl.a1 = reinterpret_cast<const uint2 *>(q)[1];
+            sl.a2 = reinterpret_cast<const uint2 *>(q)[2];
+            sl.ao = orow[xc];
+            sl.aw = kEdgeNone;
+            if (band > 0 && t == 0) sl.aw = __hip_atomic_load(&edge_in[xc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (k < 0) return; // (uniform)
         // the upper neighbour (y-1, x): the lane above finished it in the previous step
         float upf = __shfl_up(vprev, 1, 64);
         uint32_t c_above = __shfl_up(cprev, 1, 64);
         if (t == 0) { upf = 0.0f; c_above = kTopNone; } // band 0: the ring row above the interior holds 0
         if (band > 0) { // (uniform) lane 0's upper neighbour belongs to the band above
-            unsigned long long w = pre;
-            for (int spins = 0; !gave_up; ++spins) {
+            for (int spins = 0; !gave_up; ++spins) { // (only if the band above fell behind: it was ahead at start-up)
                 const bool wait = t == 0 && in && w == kEdgeNone;
                 if (!__builtin_amdgcn_ballot_w64(wait)) break;
                 if (spins > kBandSpinLimit) {
@@ -771,13 +946,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
             if (t == 0 && in) {
                 upf = __uint_as_float((uint32_t)(w >> 32));
                 c_above = (uint32_t)w;
-                if (k + 1 < iw) pre = __hip_atomic_load(&edge_in[x + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (in) {
             float v;
             if (e0.x == kTopNone) {
-                v = orow[x]; // black (0) or no candidate at all (x): fixed
+                v = omap; // black (0) or no candidate at all (x): fixed
                 lknown = false;
             } else {
                 const int up = (int)upf;
@@ -803,10 +977,10 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 uint32_t cu = 0;
                 bool cu_known = false;
                 if (up_ok && !up_listed && other_can_win) {
-                    if (slide_ok && c_above != kTopNone) cu = left_slide_down(g, c_above, x, y, up, half);
-                    else if (slide_ok && ux == x - 1 && uv == up) cu = left_slide(g, ucost, x, y, up, half);
-                    else if (slide_ok && lknown && l == up && l_ok) cu = left_slide(g, lcost, x, y, up, half);
-                    else cu = left_cost_int(g, x, y, up, half);
+                    if (slide_ok && c_above != kTopNone) cu = cost_slide_down(c_above, x, up);
+                    else if (slide_ok && ux == x - 1 && uv == up) cu = cost_slide(ucost, x, up);
+                    else if (slide_ok && lknown && l == up && l_ok) cu = cost_slide(lcost, x, up);
+                    else cu = cost_full(x, up);
                     cu_known = true;
                     double m = left_dist_of(g, cu) * g.s;
                     if (l_ok && l == up) { m *= g.s; l_listed = true; }
@@ -817,7 +991,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                     l_listed = true; // (s >= 1: neither can win)
                 }
                 if (l_ok && !l_listed && other_can_win) {
-                    const uint32_t cl = slide_ok && lknown ? left_slide(g, lcost, x, y, l, half) : left_cost_int(g, x, y, l, half);
+                    const uint32_t cl = slide_ok && lknown ? cost_slide(lcost, x, l) : cost_full(x, l);
                     const int before = b.d;
                     b.consider(left_dist_of(g, cl) * g.s, l);
                     if (b.d != before) bcost = cl;
@@ -840,16 +1014,19 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                     lknown = false;
                 }
             }
-            orow[x] = v;
             lv = v;
             vprev = v;
             cprev = lknown ? lcost : kTopNone;
-            if (hands_down) // ONE 8-byte device-scope store: the band below polls this word
-                __hip_atomic_store(&edge_out[x], ((unsigned long long)__float_as_uint(v) << 32) | cprev, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            store_x = x; // (written at the top of the next step)
         }
-        e0 = n0; e1 = n1; e2 = n2;
+    };
+    static_assert(kBandDepth == 3, "the loop below is unrolled by hand");
+    for (int k = -kBandDepth; k < nsteps; k += kBandDepth) {
+        step(k, slot[0]);
+        step(k + 1, slot[1]);
+        step(k + 2, slot[2]);
     }
+    flush_result();
 }
 
 // scratch of the raster pass behind the per-pixel candidate lists: 64 control bytes + one row of hand-off words per band
@@ -885,9 +1062,24 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     hipError_t e = hipMemsetAsync(sync + 64, 0xff, (size_t)(nbands + 1) * pitch * 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(sync, 0, 64, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ws_smooth_left_bands_kernel, dim3(nbands), dim3(kBandRows), 0, st, a, top3, g.w1,
-                       reinterpret_cast<unsigned long long *>(sync + 64), (int)pitch, reinterpret_cast<unsigned int *>(sync));
-    return hipGetLastError();
+    unsigned long long *edge = reinterpret_cast<unsigned long long *>(sync + 64);
+    unsigned int *ctrl = reinterpret_cast<unsigned int *>(sync);
+    // the planes' moving windows in LDS when the marching kernel left its planes behind and they fit
+    const int cwa = 2 * half + 66 + kBandFill, cwb = g.max_d + 2 * half + 66 + kBandFill, rp = kBandRows + 2 * half + 2;
+    const size_t lds = (size_t)(cwa + cwb) * rp * sizeof(uint32_t);
+    auto launch = [&](auto kernel, size_t bytes) -> hipError_t {
+        if (bytes > 48 * 1024) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (err != hipSuccess) return err;
+        }
+        hipLaunchKernelGGL(kernel, dim3(nbands), dim3(kBandRows), bytes, st, a, top3, g.w1, edge, (int)pitch, ctrl, cwa, cwb);
+        return hipGetLastError();
+    };
+    if (canon && lds <= 152 * 1024 && 2 * half + 1 + kBandRows <= 128) {
+        if (!a.ssd) return launch(ws_smooth_left_bands_kernel<0>, lds);
+        return a.centred ? launch(ws_smooth_left_bands_kernel<2>, lds) : launch(ws_smooth_left_bands_kernel<1>, lds);
+    }
+    return launch(ws_smooth_left_bands_kernel<-1>, 0);
 }
 
 // ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
