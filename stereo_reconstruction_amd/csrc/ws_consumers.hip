@@ -118,7 +118,19 @@ __global__ void __launch_bounds__(256) ws_box_rows_kernel(const float *__restric
     float *line = reinterpret_cast<float *>(wave_tot + 4);
     const int y = blockIdx.x, tid = threadIdx.x;
     const float *row = src + (size_t)y * sp;
-    for (int i = tid; i < w; i += 256) line[i] = row[i];
+    for (int i0 = 0; i0 < w; i0 += 8 * 256) { // eight independent loads in flight per thread, then the LDS stores
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 256 + tid;
+            v[j] = i < w ? row[i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 256 + tid;
+            if (i < w) line[i] = v[j];
+        }
+    }
     __syncthreads();
     const int per = (w + 255) / 256, i0 = tid * per, i1 = min(i0 + per, w);
     double run = 0.0;
