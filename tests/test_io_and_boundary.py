@@ -170,3 +170,31 @@ def test_example_pipeline_compiles(wslib, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, "-o", exe, os.path.join(ROOT, "examples", "pipeline_main.cpp"),
                            "-L", os.path.join(ROOT, "stereo_reconstruction_amd"), "-lws_stereo",
                            "-Wl,-rpath," + os.path.join(ROOT, "stereo_reconstruction_amd")])
+
+
+def test_planner_choices_without_a_device(wslib):
+    """ws_plan is host logic: the tiling of the BASELINE.json configs, the strip count that minimises
+    rounds x (rows + warm-up), and the candidate range clamped to what the geometry allows."""
+    ws = wslib
+    p = ws.make_params(ws.VIEW_LEFT, 7, 0, 256, 1.0, "ssd")
+    c2 = ws.plan(p, (1000, 1500, 3), (1000, 1500, 3))
+    assert c2["marching"] == 1 and c2["passes"] == 1 and c2["threads"] == 512
+    assert c2["tiles"] * c2["strips"] <= 256 and c2["tiles"] * c2["strips"] >= 240      # one round on 256 CUs
+    assert c2["strip_rows"] * c2["strips"] >= 994
+    p = ws.make_params(ws.VIEW_LEFT, 9, 0, 512, 1.0, "sad")
+    c3 = ws.plan(p, (1988, 2964, 3), (1988, 2964, 3))
+    rounds = -(-c3["tiles"] * c3["strips"] // 256)
+    assert c3["strip_rows"] >= 100 and rounds * 256 - c3["tiles"] * c3["strips"] < 32   # tall strips, full rounds
+    p = ws.make_params(ws.VIEW_LEFT, 9, 0, 1024, 1.0, "ssd")
+    assert ws.plan(p, (2160, 3840, 3), (2160, 3840, 3))["passes"] == 2                  # D = 1024: two d-group passes
+    for view in (ws.VIEW_LEFT, ws.VIEW_RIGHT):
+        for cost in ("ssd", "sad"):
+            p = ws.make_params(view, 7, 0, 3000, 1.0, cost)                              # 10 x the width
+            info = ws.plan(p, (40, 300, 3), (40, 300, 3))
+            assert info["marching"] == 1 and info["passes"] == 1, (view, cost, info)
+    # what the reference rejects is rejected without a device too
+    assert ws.validate(ws.make_params(ws.VIEW_LEFT, 6, 0, 16), (40, 100, 3), (40, 100, 3)) == -2
+    assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 7, 0, 16), (30, 100, 3), (40, 100, 3)) == -2
+    assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 3, 0, 16), (30, 100, 3), (90, 100, 3)) == 0     # bs <= 4: legal
+    assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 7, 0, 16), (39, 100, 3), (40, 100, 3)) == 0     # h2 = h1 + 1: legal
+    assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 3, 0, 16, var_block=True), (30, 100, 3), (90, 100, 3)) == -2
