@@ -303,3 +303,28 @@ def linear_py(L, R, smooth=1.0, search_range=200):
                     best, col = dist, k
             out[i, j] = float(col - j)
     return out
+
+
+def evaldisp_np(disp, gt, mask, badthresh, maxdisp, rounddisp=0):
+    """evaldisp (utils.cpp:123-168) vectorised: a third implementation beside the C oracle's loop and the
+    library's (those two follow the reference's text line by line and so read alike).  float32 throughout,
+    the error sum accumulated in float32 in row-major order like the reference's `serr += err`."""
+    d = np.asarray(disp, dtype=np.float32)
+    g = np.asarray(gt, dtype=np.float32)
+    m = np.asarray(mask)
+    known = g != np.float32(np.inf)                      # :137
+    valid = d != 0                                       # :140
+    dd = np.where(valid, np.maximum(np.float32(0), np.minimum(np.float32(maxdisp), d)), d)   # :142
+    if rounddisp:
+        dd = np.where(valid, np.floor(np.abs(dd) + np.float32(0.5)) * np.sign(dd), dd).astype(np.float32)    # round(): half away from zero
+    err = np.abs(dd - np.where(known, g, np.float32(0))).astype(np.float32)
+    counted = known & (m == 255)                         # :146
+    n = int(counted.sum())
+    bad = int((counted & valid & (err > np.float32(badthresh))).sum())
+    invalid = int((counted & ~valid).sum())
+    serr = np.float32(0)
+    for e in err[counted & valid].ravel():               # sequential float32 sum, as the reference accumulates
+        serr = np.float32(serr + e)
+    return {"n": n, "bad": float(np.float32(100.0 * bad / n)), "invalid": float(np.float32(100.0 * invalid / n)),
+            "total_bad": float(np.float32(100.0 * (bad + invalid) / n)), "avg_err": float(np.float32(serr / np.float32(n - invalid))),
+            "valid": 100.0 * n / (d.shape[0] * d.shape[1])}

@@ -126,6 +126,10 @@ def test_evaldisp_matches_the_oracle_restatement(wslib, oracle):
         a = wslib.evaldisp(disp, g["gt"], g["mask"], 2.0, 64.0, rounddisp)
         b = oracle.evaldisp(disp, g["gt"], g["mask"], 2.0, 64.0, rounddisp)
         assert a == b and a["n"] > 0 and a["invalid"] > 0
+        # the two above follow utils.cpp:123-168 line by line and read alike: a vectorised third witness
+        from oracle import brute
+        c = brute.evaldisp_np(disp, g["gt"], g["mask"], 2.0, 64.0, rounddisp)
+        assert c == a, (c, a)
 
 
 def test_cxx_facade_compiles_and_links(wslib, tmp_path):
