@@ -91,6 +91,7 @@ struct ws_context {
     hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
+    std::vector<std::pair<const void *, size_t>> batch_pins; // caller buffers registered by ws_enqueue_host until ws_wait
     int host_bands = -1;               // ws_set_host_bands: 0 = never split, -1 = automatic
     std::string err;
     std::string last_kernel;
@@ -516,6 +517,9 @@ void ws_destroy(ws_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (const auto &r : ctx->batch_pins) unpin_range(r.first, r.second);
+    ctx->batch_pins.clear();
     for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -791,6 +795,15 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     }
     uint8_t *d_left = job.d_in, *d_right = job.d_in + off_r;
     hipStream_t cs = ctx->copy_stream;
+    // registered for the life of the batch (ws_wait releases them): copies from / to pageable memory would block
+    // this thread until they are done, and the next pair's upload could not run beside this pair's search
+    {
+        const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+        const void *ptr[3] = {lin_l ? left->data : nullptr, lin_r ? right->data : nullptr, out};
+        const size_t len[3] = {span_l, span_r, ((size_t)out_stride * (oh - 1) + ow) * esz};
+        for (int i = 0; i < 3; ++i)
+            if (ptr[i] && pin_range(ptr[i], len[i])) ctx->batch_pins.emplace_back(ptr[i], len[i]);
+    }
     if (lin_l) WS_HIP(ctx, hipMemcpyAsync(d_left, left->data, span_l, hipMemcpyHostToDevice, cs));
     else WS_HIP(ctx, hipMemcpy2DAsync(d_left, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, cs));
     if (lin_r) WS_HIP(ctx, hipMemcpyAsync(d_right, right->data, span_r, hipMemcpyHostToDevice, cs));
@@ -815,8 +828,11 @@ int ws_wait(ws_context *ctx)
     WS_HIP(ctx, hipSetDevice(ctx->device));
     int rc = flush_job(ctx, ctx->jobs[ctx->job_next]); // the older one first
     if (rc == WS_OK) rc = flush_job(ctx, ctx->jobs[ctx->job_next ^ 1]);
-    WS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-    WS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
+    for (const auto &r : ctx->batch_pins) unpin_range(r.first, r.second);
+    ctx->batch_pins.clear();
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        return fail(ctx, WS_ERR_HIP, "ws_wait: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return rc;
 }
 
