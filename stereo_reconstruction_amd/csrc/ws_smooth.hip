@@ -702,6 +702,9 @@ struct LeftLds {
     int wa, wb;       // a multiple of cwa / cwb not above the window's lowest column (so c - w < 2 cw)
     __device__ __forceinline__ int pa(int c) const { const int p = c - wa; return p >= cwa ? p - cwa : p; }
     __device__ __forceinline__ int pb(int c) const { const int p = c - wb; return p >= cwb ? p - cwb : p; }
+    // dword offset of a column (24-bit multiply: full rate, and everything here is far below 2^24)
+    __device__ __forceinline__ int oa(int c) const { return __mul24(pa(c), rp); }
+    __device__ __forceinline__ int ob(int c) const { return __mul24(pb(c), rp); }
 };
 
 template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
@@ -715,7 +718,7 @@ __device__ __forceinline__ uint32_t left_pix_cost(uint32_t a, uint32_t b)
 template <int MODE>
 __device__ __forceinline__ uint32_t lds_col_cost(const LeftLds &w, int ca, int cb, int r, int n)
 {
-    const uint32_t *pa = w.A + w.pa(ca) * w.rp + r, *pb = w.B + w.pb(cb) * w.rp + r;
+    const uint32_t *pa = w.A + w.oa(ca) + r, *pb = w.B + w.ob(cb) + r;
     uint32_t acc = 0;
 #pragma unroll 4
     for (int i = 0; i < n; ++i) acc += left_pix_cost<MODE>(pa[i], pb[i]);
@@ -728,7 +731,7 @@ __device__ __forceinline__ uint32_t lds_row_cost(const LeftLds &w, int ca0, int 
 {
     uint32_t acc = 0;
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) acc += left_pix_cost<MODE>(w.A[w.pa(ca0 + i) * w.rp + r], w.B[w.pb(cb0 + i) * w.rp + r]);
+    for (int i = 0; i < n; ++i) acc += left_pix_cost<MODE>(w.A[w.oa(ca0 + i) + r], w.B[w.ob(cb0 + i) + r]);
     return acc;
 }
 
@@ -768,7 +771,11 @@ constexpr int kBandDepth = 3; // steps a pixel's inputs (candidate list, map val
 constexpr int kBandLag = 8;   // columns a band stays behind what its requests need from the band above
 constexpr int kBandFill = 5;  // steps a window column is requested ahead of its first use
 
-template <int MODE> // -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
+// BS > 0 (with MODE >= 0): the block size at compile time.  The lines of the two common sliding sums -- the upper
+// neighbour's value slid down from the row above, the left neighbour's value slid along the row -- are then read
+// from LDS at the TOP of the decision, for every lane, whether or not it will need them (8 BS registers): one wave per
+// CU has nothing else to hide an LDS round trip behind, and a step used to make fifteen to twenty of them in a row.
+template <int MODE, int BS = 0> // MODE -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
 __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
                                                                          int top_pitch, unsigned long long *edge, int edge_pitch,
                                                                          unsigned int *ctrl, int cwa, int cwb)
@@ -778,11 +785,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     unsigned int ticket = 0;
     if (t == 0) ticket = atomicAdd(&ctrl[0], 1u);
     const int band = (int)__builtin_amdgcn_readfirstlane(ticket);
-    const int half = (g.block_size - 1) / 2;
+    const int bsz = BS > 0 ? BS : g.block_size;
+    const int half = (bsz - 1) / 2;
     const int height = min(g.h1, g.h2);
     const int iw = g.w1 - 2 * half, ih = height - 2 * half; // interior
     const bool other_can_win = !(g.s >= 1.0); // (see above: for s >= 1 an unlisted neighbour value never wins)
-    const bool slide_ok = g.block_size > 2;   // (a 1-pixel window is cheaper summed than slid)
+    const bool slide_ok = bsz > 2;   // (a 1-pixel window is cheaper summed than slid)
     const int y = half + band * kBandRows + t;
     const bool row_ok = y < height - half;
     const int nrows = min(kBandRows, ih - band * kBandRows);
@@ -839,8 +847,8 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     auto cost_slide = [&](uint32_t c_prev, int x, int d) -> uint32_t {
         if constexpr (MODE >= 0) {
             const int r = y - half - win.row0;
-            return c_prev + lds_col_cost<MODE>(win, x + half + g.pad_a, x + half - d + g.pad_b, r, g.block_size) -
-                   lds_col_cost<MODE>(win, x - 1 - half + g.pad_a, x - 1 - half - d + g.pad_b, r, g.block_size);
+            return c_prev + lds_col_cost<MODE>(win, x + half + g.pad_a, x + half - d + g.pad_b, r, bsz) -
+                   lds_col_cost<MODE>(win, x - 1 - half + g.pad_a, x - 1 - half - d + g.pad_b, r, bsz);
         } else {
             return left_slide(g, c_prev, x, y, d, half);
         }
@@ -848,8 +856,8 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     auto cost_slide_down = [&](uint32_t c_up, int x, int d) -> uint32_t {
         if constexpr (MODE >= 0) {
             const int ca = x - half + g.pad_a, cb = x - half - d + g.pad_b;
-            return c_up + lds_row_cost<MODE>(win, ca, cb, y + half - win.row0, g.block_size) -
-                   lds_row_cost<MODE>(win, ca, cb, y - 1 - half - win.row0, g.block_size);
+            return c_up + lds_row_cost<MODE>(win, ca, cb, y + half - win.row0, bsz) -
+                   lds_row_cost<MODE>(win, ca, cb, y - 1 - half - win.row0, bsz);
         } else {
             return left_slide_down(g, c_up, x, y, d, half);
         }
@@ -857,8 +865,8 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     auto cost_full = [&](int x, int d) -> uint32_t {
         if constexpr (MODE >= 0) {
             uint32_t acc = 0;
-            for (int i = 0; i < g.block_size; ++i)
-                acc += lds_col_cost<MODE>(win, x - half + i + g.pad_a, x - half + i - d + g.pad_b, y - half - win.row0, g.block_size);
+            for (int i = 0; i < bsz; ++i)
+                acc += lds_col_cost<MODE>(win, x - half + i + g.pad_a, x - half + i - d + g.pad_b, y - half - win.row0, bsz);
             return acc;
         } else {
             return left_cost_int(g, x, y, d, half);
@@ -928,8 +936,9 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         }
         if (k < 0) return; // (uniform)
         // the upper neighbour (y-1, x): the lane above finished it in the previous step
-        float upf = __shfl_up(vprev, 1, 64);
-        uint32_t c_above = __shfl_up(cprev, 1, 64);
+        // (wave_shr:1 -- one DPP move each; __shfl_up goes through the LDS crossbar and its latency)
+        float upf = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(vprev), 0x138, 0xf, 0xf, false));
+        uint32_t c_above = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cprev, 0x138, 0xf, 0xf, false);
         if (t == 0) { upf = 0.0f; c_above = kTopNone; } // band 0: the ring row above the interior holds 0
         if (band > 0) { // (uniform) lane 0's upper neighbour belongs to the band above
             for (int spins = 0; !gave_up; ++spins) { // (only if the band above fell behind: it was ahead at start-up)
@@ -948,6 +957,38 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 c_above = (uint32_t)w;
             }
         }
+        // (BS > 0) the lines the two common sliding sums would need, requested now
+        constexpr int NB = BS > 0 ? BS : 1;
+        uint32_t da_in[NB], db_in[NB], da_out[NB], db_out[NB]; // `up` slid down: window rows y + half (in) / y - 1 - half (out)
+        uint32_t sa_in[NB], sb_in[NB], sa_out[NB], sb_out[NB]; // `l` slid right: window columns x + half (in) / x - 1 - half (out)
+        if (MODE >= 0 && BS > 0 && other_can_win) { // (uniform)
+            const int xq = half + min(max(xs, 1), iw - 1);                  // (lanes outside their row read somewhere harmless)
+            const int du = min(max((int)upf, 1), g.max_d), dl = min(max((int)lv, 1), g.max_d);
+            const int r_in = y + half - win.row0, r_out = y - 1 - half - win.row0, r_col = y - half - win.row0;
+            const uint32_t *pca_in = win.A + win.oa(xq + half + g.pad_a) + r_col, *pca_out = win.A + win.oa(xq - 1 - half + g.pad_a) + r_col;
+            const uint32_t *pcb_in = win.B + win.ob(xq + half - dl + g.pad_b) + r_col, *pcb_out = win.B + win.ob(xq - 1 - half - dl + g.pad_b) + r_col;
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                const int ia = win.oa(xq - half + i + g.pad_a), ib = win.ob(xq - half + i - du + g.pad_b);
+                da_in[i] = win.A[ia + r_in]; db_in[i] = win.B[ib + r_in];
+                da_out[i] = win.A[ia + r_out]; db_out[i] = win.B[ib + r_out];
+                sa_in[i] = pca_in[i]; sb_in[i] = pcb_in[i];
+                sa_out[i] = pca_out[i]; sb_out[i] = pcb_out[i];
+            }
+        }
+        auto pre_slide_down = [&](uint32_t c_up) -> uint32_t {
+            uint32_t acc = c_up;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_in[i], db_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_out[i], db_out[i]);
+            return acc;
+        };
+        auto pre_slide = [&](uint32_t c_prev) -> uint32_t {
+            uint32_t acc = c_prev;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_in[i], sb_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_out[i], sb_out[i]);
+            return acc;
+        };
+        constexpr bool PRE = MODE >= 0 && BS > 0;
         if (in) {
             float v;
             if (e0.x == kTopNone) {
@@ -977,7 +1018,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 uint32_t cu = 0;
                 bool cu_known = false;
                 if (up_ok && !up_listed && other_can_win) {
-                    if (slide_ok && c_above != kTopNone) cu = cost_slide_down(c_above, x, up);
+                    if (slide_ok && c_above != kTopNone) cu = PRE ? pre_slide_down(c_above) : cost_slide_down(c_above, x, up);
                     else if (slide_ok && ux == x - 1 && uv == up) cu = cost_slide(ucost, x, up);
                     else if (slide_ok && lknown && l == up && l_ok) cu = cost_slide(lcost, x, up);
                     else cu = cost_full(x, up);
@@ -991,7 +1032,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                     l_listed = true; // (s >= 1: neither can win)
                 }
                 if (l_ok && !l_listed && other_can_win) {
-                    const uint32_t cl = slide_ok && lknown ? cost_slide(lcost, x, l) : cost_full(x, l);
+                    const uint32_t cl = slide_ok && lknown ? (PRE ? pre_slide(lcost) : cost_slide(lcost, x, l)) : cost_full(x, l);
                     const int before = b.d;
                     b.consider(left_dist_of(g, cl) * g.s, l);
                     if (b.d != before) bcost = cl;
@@ -1076,8 +1117,19 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
         return hipGetLastError();
     };
     if (canon && lds <= 152 * 1024 && 2 * half + 1 + kBandRows <= 128) {
-        if (!a.ssd) return launch(ws_smooth_left_bands_kernel<0>, lds);
-        return a.centred ? launch(ws_smooth_left_bands_kernel<2>, lds) : launch(ws_smooth_left_bands_kernel<1>, lds);
+        // (block sizes of the BASELINE configs and of the reference's own call get the compile-time form)
+#define WS_LEFT_BS(MODE)                                                                              \
+        switch (g.block_size) {                                                                       \
+        case 5: return launch(ws_smooth_left_bands_kernel<MODE, 5>, lds);                             \
+        case 7: return launch(ws_smooth_left_bands_kernel<MODE, 7>, lds);                             \
+        case 9: return launch(ws_smooth_left_bands_kernel<MODE, 9>, lds);                             \
+        case 17: return launch(ws_smooth_left_bands_kernel<MODE, 17>, lds);                           \
+        default: return launch(ws_smooth_left_bands_kernel<MODE, 0>, lds);                            \
+        }
+        if (!a.ssd) { WS_LEFT_BS(0) }
+        if (a.centred) { WS_LEFT_BS(2) }
+        WS_LEFT_BS(1)
+#undef WS_LEFT_BS
     }
     return launch(ws_smooth_left_bands_kernel<-1>, 0);
 }
