@@ -541,8 +541,23 @@ __device__ __forceinline__ bool left_better(double dist, int d, double bdist, in
     return dist < bdist || (dist == bdist && d > bd);
 }
 
-// the three best candidates of a pixel: (cost, d) x 3, kTopNone = no such candidate
+// the three best candidates of a pixel: (cost, d, distance) x 3, kTopNone = no such candidate.  The distance --
+// cv::norm of the window, sqrt(cost) in double for SSD (BlockSearch.cpp:66) -- is taken here, by the data-parallel
+// pre-pass, so that the raster pass does not spend its one wave's issue slots on three double square roots a step.
 constexpr uint32_t kTopNone = 0xffffffffu; // above any window cost (63 * 63 * 3 * 255^2 < 2^30)
+constexpr int kTopWords = 12;              // dwords per pixel: 3 x {cost, d, distance lo, distance hi}
+
+__device__ __forceinline__ void left_store_entry(const SmoothLeftArgs &g, uint32_t *t, uint32_t c0, int d0, uint32_t c1, int d1,
+                                                 uint32_t c2, int d2)
+{
+    const uint32_t c[3] = {c0, c1, c2};
+    const int d[3] = {d0, d1, d2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double m = c[i] == kTopNone ? 0.0 : left_dist_of(g, c[i]);
+        reinterpret_cast<uint4 *>(t)[i] = make_uint4(c[i], (uint32_t)d[i], (uint32_t)__double2loint(m), (uint32_t)__double2hiint(m));
+    }
+}
 
 __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
 {
@@ -566,10 +581,7 @@ __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs 
             }
         }
     }
-    uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
-    reinterpret_cast<uint2 *>(t)[0] = make_uint2(c0, (uint32_t)d0);
-    reinterpret_cast<uint2 *>(t)[1] = make_uint2(c1, (uint32_t)d1);
-    reinterpret_cast<uint2 *>(t)[2] = make_uint2(c2, (uint32_t)d2);
+    left_store_entry(g, top + ((size_t)y * top_pitch + x) * kTopWords, c0, d0, c1, d1, c2, d2);
 }
 
 // the reference's running minimum: 'min' starts at DBL_MAX with no winner, d descending, strict '<'
@@ -614,10 +626,7 @@ __global__ void __launch_bounds__(256) ws_left_cost_kernel(const SmoothLeftArgs 
             }
         }
     }
-    uint32_t *t = top + ((size_t)y * top_pitch + x) * 6;
-    reinterpret_cast<uint2 *>(t)[0] = make_uint2(c[0], (uint32_t)dd[0]);
-    reinterpret_cast<uint2 *>(t)[1] = make_uint2(c[1], (uint32_t)dd[1]);
-    reinterpret_cast<uint2 *>(t)[2] = make_uint2(c[2], (uint32_t)dd[2]);
+    left_store_entry(g, top + ((size_t)y * top_pitch + x) * kTopWords, c[0], dd[0], c[1], dd[1], c[2], dd[2]);
 }
 
 // Sliding window sums.  The cost of (x, y, d) follows from the cost of (x-1, y, d) -- one window
@@ -768,7 +777,7 @@ constexpr unsigned long long kEdgeNone = ~0ull;
 constexpr int kBandSpinLimit = 1 << 20;
 
 constexpr int kBandDepth = 3; // steps a pixel's inputs (candidate list, map value, hand-off word) are requested ahead
-constexpr int kBandLag = 8;   // columns a band stays behind what its requests need from the band above
+constexpr int kBandLag = 5;   // columns a band stays behind what its requests need from the band above
 constexpr int kBandFill = 5;  // steps a window column is requested ahead of its first use
 
 // BS > 0 (with MODE >= 0): the block size at compile time.  The lines of the two common sliding sums -- the upper
@@ -800,7 +809,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     unsigned long long *edge_out = edge + (size_t)(band + 1) * edge_pitch;
     const bool hands_down = t == nrows - 1 && (band + 1) * kBandRows < ih;
     float *orow = g.out + (size_t)min(y, height - 1) * g.out_pitch;
-    const uint32_t *trow = top + (size_t)min(y, height - 1) * top_pitch * 6;
+    const uint32_t *trow = top + (size_t)min(y, height - 1) * top_pitch * kTopWords;
     // the lane's running state along its row
     float lv = 0.0f;          // value of (y, x-1); the ring column left of the interior holds 0
     uint32_t lcost = 0;       // window cost of (x-1, lv) ...
@@ -893,11 +902,11 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     // kBandFill > kBandDepth steps ahead has landed once the loads of the same step have been consumed.)
     // The queue is kBandDepth register slots used round-robin by a loop unrolled kBandDepth times (no moves: a move
     // would have to wait for the load it moves).
-    struct Slot { uint2 a0, a1, a2; float ao; unsigned long long aw; };
+    struct Slot { uint4 a0, a1, a2; float ao; unsigned long long aw; };
     Slot slot[kBandDepth];
 #pragma unroll
     for (int i = 0; i < kBandDepth; ++i) {
-        slot[i].a0 = slot[i].a1 = slot[i].a2 = make_uint2(kTopNone, 0u);
+        slot[i].a0 = slot[i].a1 = slot[i].a2 = make_uint4(kTopNone, 0u, 0u, 0u);
         slot[i].ao = 0.0f;
         slot[i].aw = kEdgeNone;
     }
@@ -919,17 +928,18 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
             }
         }
         // this step's inputs leave their slot, the inputs of step k + kBandDepth take it
-        const uint2 e0 = sl.a0, e1 = sl.a1, e2 = sl.a2;
+        const uint4 e0 = sl.a0, e1 = sl.a1, e2 = sl.a2;
         const float omap = sl.ao;
         unsigned long long w = sl.aw;
         {
             const int xn = xs + kBandDepth; // (clamped, not branched: every step issues the same loads)
             const bool on = row_ok && xn >= 0 && xn < iw;
             const int xc = half + min(max(xn, 0), iw - 1);
-            const uint32_t *q = trow + (size_t)xc * 6;
-            sl.a0 = on ? reinterpret_cast<const uint2 *>(q)[0] : make_uint2(kTopNone, 0u);
-            sl.a1 = reinterpret_cast<const uint2 *>(q)[1];
-            sl.a2 = reinterpret_cast<const uint2 *>(q)[2];
+            const uint32_t *q = trow + (size_t)xc * kTopWords;
+            sl.a0 = reinterpret_cast<const uint4 *>(q)[0];
+            if (!on) sl.a0.x = kTopNone;
+            sl.a1 = reinterpret_cast<const uint4 *>(q)[1];
+            sl.a2 = reinterpret_cast<const uint4 *>(q)[2];
             sl.ao = orow[xc];
             sl.aw = kEdgeNone;
             if (band > 0 && t == 0) sl.aw = __hip_atomic_load(&edge_in[xc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -977,12 +987,14 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
             }
         }
         auto pre_slide_down = [&](uint32_t c_up) -> uint32_t {
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): ONE wait for all the lines instead of one per dword
             uint32_t acc = c_up;
 #pragma unroll
             for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_in[i], db_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_out[i], db_out[i]);
             return acc;
         };
         auto pre_slide = [&](uint32_t c_prev) -> uint32_t {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             uint32_t acc = c_prev;
 #pragma unroll
             for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_in[i], sb_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_out[i], sb_out[i]);
@@ -1002,12 +1014,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 LeftBest b{1.7976931348623157e308, -1};
                 uint32_t bcost = 0; // integer window cost of the running winner
                 bool up_listed = false, l_listed = false;
-                const uint2 es[3] = {e0, e1, e2};
+                const uint4 es[3] = {e0, e1, e2};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (es[i].x == kTopNone) continue;
                     const int d = (int)es[i].y;
-                    double m = left_dist_of(g, es[i].x);
+                    double m = __hiloint2double((int)es[i].w, (int)es[i].z); // the pre-pass took the root
                     if (up_ok && up == d) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
                     if (l_ok && l == d) { m *= g.s; l_listed = true; }    // the left factor second (:71-73)
                     const int before = b.d;
@@ -1074,7 +1086,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
 static size_t smooth_left_edge_pitch(int w) { return (size_t)((w + 15) & ~15); }
 static size_t smooth_left_sync_bytes(int w, int h) { return 64 + ((size_t)h / kBandRows + 2) * smooth_left_edge_pitch(w) * 8; }
 
-size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * 6 * sizeof(uint32_t) + smooth_left_sync_bytes(w, h); }
+size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h); }
 
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
                               hipStream_t st)
@@ -1097,7 +1109,7 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     else
         hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
     // hand-off words all ones ("not there yet"), ticket and error words zero
-    uint8_t *sync = reinterpret_cast<uint8_t *>(top3) + (size_t)g.w1 * g.h1 * 6 * sizeof(uint32_t);
+    uint8_t *sync = reinterpret_cast<uint8_t *>(top3) + (size_t)g.w1 * g.h1 * kTopWords * sizeof(uint32_t);
     const int nbands = ceil_div(ih, kBandRows);
     const size_t pitch = smooth_left_edge_pitch(g.w1);
     hipError_t e = hipMemsetAsync(sync + 64, 0xff, (size_t)(nbands + 1) * pitch * 8, st);
