@@ -732,3 +732,22 @@ def test_host_call_in_bands_equals_the_plain_call(wslib, oracle, view):
         auto = ctx.search(p, big_l, big_r, dtype=np.float64)
         ctx.set_host_bands(0)
         assert np.array_equal(auto, ctx.search(p, big_l, big_r, dtype=np.float64))
+
+
+@pytest.mark.parametrize("shape", [(60, 1300), (200, 700), (97, 130)])
+def test_left_smooth_factor_across_many_row_bands(wslib, gpu_ctx, oracle, shape):
+    """The left view's raster pass runs in bands of 64 rows on separate CUs that hand their last row down through
+    device-scope words (ws_smooth.hip): tall images (up to 21 bands here), every kind of window line source
+    (LDS windows with compile-time and run-time block sizes, global memory for windows without planes), a factor
+    inside and one outside [0, 1], tie-heavy content."""
+    w, h = shape
+    rng = np.random.default_rng(w + h)
+    left, right, _ = make_pair(w, h, 40, seed=w)
+    tl = (rng.integers(0, 3, size=(h, w, 3)) * 120).astype(np.uint8)
+    tr = (rng.integers(0, 3, size=(h, w, 3)) * 120).astype(np.uint8)
+    left[h // 3:h // 3 + 5, 10:30] = 0
+    for L, R in ((left, right), (tl, tr)):
+        for bs, cost, maxd, s in ((7, "ssd", 40, 0.9), (11, "sad", 24, 0.5), (17, "ssd", 30, 0.9), (19, "ssd", 12, 0.9), (5, "ssd", 40, 1.4)):
+            got = wslib.BlockSearch(L, R, bs, 0, maxd, cost=cost, context=gpu_ctx).computeDisparityMapLeft(s)
+            want = oracle.block_left(L, R, bs, 0, maxd, smooth=s, cost=cost)
+            assert np.array_equal(got, want), (shape, bs, cost, s)
