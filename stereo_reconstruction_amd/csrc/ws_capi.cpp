@@ -104,6 +104,7 @@ struct ws_context {
     int last_skip[4] = {0, 0, 0, 0};
     bool want_cost = false;       // run_search: also leave the winners' costs (right view, smoothFactor)
     int32_t *last_cost = nullptr; // where it left them (pitch = plane width), or null
+    double *direct_f64 = nullptr; // run_search: the kernels store the map as doubles here (CV_64F out without a widening pass)
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
 };
 
@@ -346,6 +347,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.block_size = p->block_size; ga.min_d = p->min_disparity; ga.max_d = p->max_disparity;
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
+    ga.out64 = ctx->direct_f64;
 
     ctx->last_cost = nullptr;
     if (p->view == WS_VIEW_RIGHT) ctx->var_block_ran = false;
@@ -408,7 +410,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
             cost_out = static_cast<int32_t *>(ctx->cost.p);
         }
         ctx->last_cost = cost_out;
-        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, out_stride, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
+        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, ctx->direct_f64, out_stride, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;
@@ -440,6 +442,27 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         if (march) WS_HIP(ctx, launch_refine_planes(c, m, ring_a, ring_b, ring_bi, out, out_stride, s));
         WS_HIP(ctx, launch_refine(ga, s)); // the pixels outside the marching interior (all of them without it)
     }
+    return WS_OK;
+}
+
+// A search whose kernels only ever WRITE the map (smoothFactor 1, no sub-pixel refine, no varBlock: the marching
+// kernel's flush, the border ring, LinearSearch, the brute force) can store it as doubles itself: CV_64F output
+// then needs neither a second plane nor a widening pass.
+bool writes_only(const ws_params *p) { return p->smooth_factor == 1.0 && !p->subpixel && !(p->var_block && p->view == WS_VIEW_RIGHT); }
+
+int run_device_f64(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R, float *scratch32, double *out64,
+                   int ow, int rows, hipStream_t s)
+{
+    // scratch32: a float map of the same size for the calls that read their own output (widened afterwards)
+    if (writes_only(p)) {
+        ctx->direct_f64 = out64;
+        const int rc = run_device(ctx, p, L, R, scratch32, ow, s);
+        ctx->direct_f64 = nullptr;
+        return rc;
+    }
+    const int rc = run_device(ctx, p, L, R, scratch32, ow, s);
+    if (rc != WS_OK) return rc;
+    WS_HIP(ctx, launch_widen(scratch32, ow, out64, ow, ow, rows, s));
     return WS_OK;
 }
 
@@ -613,7 +636,7 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_right, span_r)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * (H + 2 * half * nb) * 4)) != WS_OK) return rc;
-    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * H * 8)) != WS_OK) return rc;
+    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * (H + 2 * half * nb) * 8)) != WS_OK) return rc;
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     uint8_t *dl = static_cast<uint8_t *>(ctx->d_left.p), *dr = static_cast<uint8_t *>(ctx->d_right.p);
     float *scratch = static_cast<float *>(ctx->d_out.p);
@@ -644,13 +667,13 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         ws_image bl{dl + (size_t)a * left->stride, left->width, b - a, left->stride};
         ws_image br{dr + (size_t)a * right->stride, right->width, b - a, right->stride};
         float *bout = scratch + (size_t)ow * (a + 2 * half * k); // the band's own map: its border rows are scrap
-        if ((rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream)) != WS_OK) return rc;
-        const float *valid = bout + (size_t)ow * (y0 - a);
-        const void *src = valid;
-        if (out_dtype == WS_OUT_F64) {
-            double *d64 = static_cast<double *>(ctx->d_out64.p) + (size_t)ow * y0;
-            WS_HIP(ctx, launch_widen(valid, ow, d64, ow, ow, y1 - y0, ctx->stream));
-            src = d64;
+        const void *src = bout + (size_t)ow * (y0 - a);
+        if (out_dtype == WS_OUT_F64) { // (doubles straight from the search kernels where they only write the map)
+            double *bout64 = static_cast<double *>(ctx->d_out64.p) + (size_t)ow * (a + 2 * half * k);
+            if ((rc = run_device_f64(ctx, p, &bl, &br, bout, bout64, ow, b - a, ctx->stream)) != WS_OK) return rc;
+            src = bout64 + (size_t)ow * (y0 - a);
+        } else if ((rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream)) != WS_OK) {
+            return rc;
         }
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
         WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
@@ -723,13 +746,14 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
     ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
     float *dout = static_cast<float *>(ctx->d_out.p);
-    if ((rc = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) return rc;
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     const void *src = dout;
     if (out_dtype == WS_OUT_F64) {
         if ((rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
-        WS_HIP(ctx, launch_widen(dout, ow, static_cast<double *>(ctx->d_out64.p), ow, ow, oh, s));
+        if ((rc = run_device_f64(ctx, p, &dl, &dr, dout, static_cast<double *>(ctx->d_out64.p), ow, oh, s)) != WS_OK) return rc;
         src = ctx->d_out64.p;
+    } else if ((rc = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) {
+        return rc;
     }
     if (out_stride == ow)
         WS_HIP(ctx, hipMemcpyAsync(out, src, (size_t)ow * oh * esz, hipMemcpyDeviceToHost, s));
@@ -812,8 +836,11 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, job.ev_h2d, 0));
     ws_image dl{d_left, left->width, left->height, lin_l ? left->stride : (int)lb};
     ws_image dr{d_right, right->width, right->height, lin_r ? right->stride : (int)rb};
-    if ((rc = run_device(ctx, p, &dl, &dr, job.d_out, ow, ctx->stream)) != WS_OK) return rc;
-    if (out_dtype == WS_OUT_F64) WS_HIP(ctx, launch_widen(job.d_out, ow, job.d_out64, ow, ow, oh, ctx->stream));
+    if (out_dtype == WS_OUT_F64) {
+        if ((rc = run_device_f64(ctx, p, &dl, &dr, job.d_out, job.d_out64, ow, oh, ctx->stream)) != WS_OK) return rc;
+    } else if ((rc = run_device(ctx, p, &dl, &dr, job.d_out, ow, ctx->stream)) != WS_OK) {
+        return rc;
+    }
     WS_HIP(ctx, hipEventRecord(job.ev_done, ctx->stream));
     job.user_out = out; job.w = ow; job.h = oh; job.out_stride = out_stride; job.dtype = out_dtype;
     job.pending = true;

@@ -177,7 +177,8 @@ __device__ __forceinline__ void generic_pixel(const GenericArgs &g, long long id
             val = (float)(col - x);
         }
     }
-    g.out[(size_t)y * g.out_pitch + x] = val;
+    if (g.out64) g.out64[(size_t)y * g.out_pitch + x] = (double)val;
+    else g.out[(size_t)y * g.out_pitch + x] = val;
 }
 
 // wave-wide sum by a butterfly of shuffles

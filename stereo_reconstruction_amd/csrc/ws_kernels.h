@@ -66,8 +66,8 @@ hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *s
                           hipStream_t s);
 // keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
-                        hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2)
+                        float *out, double *out64, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
+                        hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2); out64: see GenericArgs
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 bool march_has_cost(const Canon &c); // is there an instantiation that also writes cost_out?
 
@@ -81,6 +81,7 @@ struct GenericArgs {
     int skip_x0, skip_x1, skip_y0, skip_y1;
     float *out;
     int out_pitch;
+    double *out64; // if set, the search kernels store doubles here (same pitch, in elements) instead of floats to `out`
     // varBlock (right view): per-pixel block size chosen by ws_varblock_kernel, or null
     const int16_t *bs_plane;
     int bs_pitch;

@@ -46,6 +46,7 @@ struct MarchArgs {
     const uint32_t *B;
     const int32_t *bias; // SSD only
     float *out;
+    double *out64; // if set: doubles here instead of floats to `out` (CV_64F output without a widening pass)
     int pitch_a, pad_a, pitch_b, pad_b, pitch_bi, pad_bi, out_pitch;
     int wa;
     int nxr, nch;
@@ -316,7 +317,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     }
                     // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
                     if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
-                    g.out[(size_t)y * g.out_pitch + xo] = val;
+                    if (g.out64) g.out64[(size_t)y * g.out_pitch + xo] = (double)val;
+                    else g.out[(size_t)y * g.out_pitch + xo] = val;
                     if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
                         int32_t cst;
                         if constexpr (SSD) cst = (int32_t)((long long)key >> 32) >> LT;
@@ -553,7 +555,7 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &)
 }
 
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
+                        float *out, double *out64, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
                         hipStream_t s)
 {
     const MarchEntry *e = find_march(c);
@@ -565,6 +567,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.pitch_bi = bias.pitch;
     g.pad_bi = bias.pad;
     g.out = out;
+    g.out64 = out64;
     g.pitch_a = a.pitch;
     g.pad_a = a.pad;
     g.pitch_b = b.pitch;
