@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) ws_left_cost_kernel(const SmoothLeftArgs 
 
 // Sliding window sums.  The cost of (x, y, d) follows from the cost of (x-1, y, d) -- one window
 // column enters, one leaves -- or from the cost of (x, y-1, d) -- one window row enters, one leaves.
-// The raster pass is ONE workgroup whose step time is the latency of these sums, so on the planes
+// The raster pass is one wave per band whose step time is the latency of these sums, so on the planes
 // the loads of both lines are issued in batches of 8 pixels (clamped index, the tail masked) rather
 // than one dependent load after the other.
 template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
@@ -699,9 +699,9 @@ __device__ __forceinline__ uint32_t left_slide_down(const SmoothLeftArgs &g, uin
 // A step of the raster pass is a chain of dependent loads (which neighbour value, then that value's window
 // line) with one wave per CU: its length is load latency.  So each band keeps the part of both dword planes
 // its diagonal can touch in LDS: rows [band's first row - half - 1, last row + half], and a circular window of
-// columns -- plane A the 2 half + 68 columns up to the diagonal's head, plane B max_d more to the left.
+// columns -- plane A the 2 half + 66 + kBandFill columns up to the diagonal's head, plane B max_d more to the left.
 // Column-major (a column's rows are contiguous, the lanes of a diagonal -- one row down, one column left each
-// -- fall on different banks because rp - 1 is odd).  Every step one new column per plane is requested two
+// -- fall on different banks because rp - 1 is odd).  Every step one new column per plane is requested kBandFill
 // steps ahead by LDS-DMA (global_load_lds_dword: lane = row, strided source, contiguous destination) and a
 // column that leaves the window is overwritten cw columns later.
 struct LeftLds {
