@@ -32,12 +32,19 @@ def ref(oracle, view, left, right, bs, mind, maxd, cost, subpixel=False, rows=No
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden_fixtures(wslib, gpu_ctx, name):
     g = load_golden(name)
+    s = float(g.get("smooth", 1.0))            # round-2 fixtures (tools/make_golden_r2.py) carry smoothFactor / varBlock
     if g["view"] == "linear":
         out = wslib.LinearSearch(g["left"], g["right"], context=gpu_ctx,
-                                 search_range=g["max_disparity"]).computeDisparityMap(1.0)
+                                 search_range=g["max_disparity"]).computeDisparityMap(s)
     else:
-        out = run(wslib, gpu_ctx, g["view"], g["left"], g["right"], g["block_size"],
-                  g["min_disparity"], g["max_disparity"], g["cost"])
+        b = wslib.BlockSearch(g["left"], g["right"], g["block_size"], g["min_disparity"], g["max_disparity"], cost=g["cost"],
+                              context=gpu_ctx)
+        if g["view"] == "left":
+            out = b.computeDisparityMapLeft(s)
+        else:
+            out = b.computeDisparityMapRight(s, bool(g.get("var_block", 0)), float(g.get("thres", 19.0)))
+            if g.get("var_block", 0):
+                assert gpu_ctx.last_max_block(g["block_size"]) == g["max_block"]
     assert out.dtype == np.float64
     assert np.array_equal(out, g["expected"].astype(np.float64))
 

@@ -10,12 +10,16 @@ from conftest import golden_cases, load_golden
 def test_oracle_reproduces_golden(oracle, name):
     g = load_golden(name)
     args = (g["left"], g["right"], g["block_size"], g["min_disparity"], g["max_disparity"])
+    s = float(g.get("smooth", 1.0))            # round-2 fixtures (tools/make_golden_r2.py) carry smoothFactor / varBlock
     if g["view"] == "left":
-        out = oracle.block_left(*args, cost=g["cost"])
+        out = oracle.block_left(*args, smooth=s, cost=g["cost"])
     elif g["view"] == "right":
-        out = oracle.block_right(*args, cost=g["cost"])
+        out, mb = oracle.block_right(*args, smooth=s, var_block=bool(g.get("var_block", 0)), thres=float(g.get("thres", 19.0)),
+                                     cost=g["cost"], return_max_block=True)
+        if g.get("var_block", 0):
+            assert mb == g["max_block"]
     else:
-        out = oracle.linear(g["left"], g["right"], search_range=g["max_disparity"])
+        out = oracle.linear(g["left"], g["right"], smooth=s, search_range=g["max_disparity"])
     assert np.array_equal(out, g["expected"].astype(np.float64))
 
 
