@@ -735,32 +735,48 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_right, span_r)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * oh * 4)) != WS_OK) return rc;
-    if (lin_l)
-        WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, left->data, span_l, hipMemcpyHostToDevice, s));
-    else
-        WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, s));
-    if (lin_r)
-        WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, right->data, span_r, hipMemcpyHostToDevice, s));
-    else
-        WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_right.p, rb, right->data, right->stride, rb, right->height, hipMemcpyHostToDevice, s));
-    ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
-    ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
-    float *dout = static_cast<float *>(ctx->d_out.p);
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
-    const void *src = dout;
-    if (out_dtype == WS_OUT_F64) {
-        if ((rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
-        if ((rc = run_device_f64(ctx, p, &dl, &dr, dout, static_cast<double *>(ctx->d_out64.p), ow, oh, s)) != WS_OK) return rc;
-        src = ctx->d_out64.p;
-    } else if ((rc = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) {
-        return rc;
-    }
-    if (out_stride == ow)
-        WS_HIP(ctx, hipMemcpyAsync(out, src, (size_t)ow * oh * esz, hipMemcpyDeviceToHost, s));
-    else
-        WS_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride * esz, src, (size_t)ow * esz, (size_t)ow * esz, oh, hipMemcpyDeviceToHost, s));
-    WS_HIP(ctx, hipStreamSynchronize(s));
-    return WS_OK;
+    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
+    // The caller's buffers are registered for the call here too, like in the banded and the batched path: every
+    // host copy of this library then goes the same way, whatever the band setting of the moment, instead of a
+    // buffer being pinned by the runtime behind the scenes in one call (its path for pageable copies of a
+    // megabyte and more) and registered by us in the next.
+    const size_t span_o = ((size_t)out_stride * (oh - 1) + ow) * esz;
+    const bool pin_l = lin_l && pin_range(left->data, span_l), pin_r = lin_r && pin_range(right->data, span_r);
+    const bool pin_o = pin_range(out, span_o);
+    rc = [&]() -> int {
+        if (lin_l)
+            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, left->data, span_l, hipMemcpyHostToDevice, s));
+        else
+            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, s));
+        if (lin_r)
+            WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, right->data, span_r, hipMemcpyHostToDevice, s));
+        else
+            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_right.p, rb, right->data, right->stride, rb, right->height, hipMemcpyHostToDevice, s));
+        ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
+        ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
+        float *dout = static_cast<float *>(ctx->d_out.p);
+        const void *src = dout;
+        int rc2;
+        if (out_dtype == WS_OUT_F64) {
+            if ((rc2 = run_device_f64(ctx, p, &dl, &dr, dout, static_cast<double *>(ctx->d_out64.p), ow, oh, s)) != WS_OK) return rc2;
+            src = ctx->d_out64.p;
+        } else if ((rc2 = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) {
+            return rc2;
+        }
+        if (out_stride == ow)
+            WS_HIP(ctx, hipMemcpyAsync(out, src, (size_t)ow * oh * esz, hipMemcpyDeviceToHost, s));
+        else
+            WS_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride * esz, src, (size_t)ow * esz, (size_t)ow * esz, oh, hipMemcpyDeviceToHost, s));
+        return WS_OK;
+    }();
+    // (also after an error: nothing may still be copying when the ranges are released)
+    const hipError_t es = hipStreamSynchronize(s);
+    if (pin_l) unpin_range(left->data, span_l);
+    if (pin_r) unpin_range(right->data, span_r);
+    if (pin_o) unpin_range(out, span_o);
+    if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "host call: %s", hipGetErrorString(es));
+    return rc;
 }
 
 // The batched host path keeps two pairs in flight: while one is searched (context stream) the next

@@ -1149,109 +1149,238 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
 // ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
 // There c0 * s^k does not grow with k, so t_0 >= t_1 >= t_2 and a pixel is one of: always 0
 // ("generate"), never 0 ("kill"), or 0 exactly when its left neighbour is ("propagate") -- a
-// carry chain.  With the codes packed into bit planes (64 columns per word) one lane resolves 64
-// columns with a single 64-bit addition (A = g|p, B = g: the carries of A+B are the chain), and
-// the carries between the lanes' words come from the same addition on two ballot masks in the
-// scalar unit.  ~40 bit operations per row for the whole image width.
-__global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__restrict__ sel, int sel_pitch, int w,
-                                                               unsigned long long *__restrict__ planes, int nwp)
+// carry chain.  With the codes packed into bit planes one lane resolves a word of columns with a
+// single addition (A = g|p, B = g: the carries of A+B are the chain).  Words hold 31 (63 for
+// images wider than 1984) columns, so the carry out of a word is the top bit of the sum.
+// The words of a row are skewed in time: lane l works on row t - l at step t, so the carry into
+// its word is what lane l-1 produced one step earlier (one DPP shift) and the flags of the row
+// above are its own previous result -- a systolic array in one wave, no scalar unit, no ballots.
+// A lone wave issues an instruction every ~8 ns whatever it is, so the step is counted in
+// instructions: 6 of arithmetic, one LDS read, and a wait / store / address update per 4 steps.
+// The planes are stored the way the lanes walk them: per LDS chunk, per word, the skewed rows
+// (word l of image row y is skewed row y + l) one entry after the other.
+template <typename W> struct alignas(4 * sizeof(W)) PlaneEntry { W n0, n1, n2, pad; }; // one LDS read (b128) or two
+
+template <typename W> struct BitsLayout {
+    static constexpr int kBits = 8 * (int)sizeof(W) - 1; // columns per word
+    int nw, steps, chunk_rows, nchunks;
+    size_t plane_entries, z_words;
+    __host__ BitsLayout(int w, int rows)
+    {
+        nw = ceil_div(w, kBits);
+        steps = round_up(rows + nw, 8);
+        // two chunks of (chunk_rows + 1) entries per word in ~48 KB of LDS; the odd entry keeps the lanes on different banks
+        chunk_rows = (int)(24576 / ((size_t)nw * sizeof(PlaneEntry<W>)) - 1) / 8 * 8;
+        if (chunk_rows > 64) chunk_rows = 64;
+        if (chunk_rows < 8) chunk_rows = 8;
+        nchunks = ceil_div(steps, chunk_rows);
+        plane_entries = (size_t)nchunks * nw * (chunk_rows + 1);
+        z_words = (size_t)nw * nchunks * chunk_rows + 8; // + the idle lanes' scratch
+    }
+    __host__ int z_pitch() const { return nchunks * chunk_rows; }
+    __host__ size_t bytes() const { return plane_entries * sizeof(PlaneEntry<W>) + z_words * sizeof(W) + 64; }
+    __host__ size_t chunk_bytes() const { return (size_t)nw * (chunk_rows + 1) * sizeof(PlaneEntry<W>); }
+    __host__ size_t lds_bytes() const { return 2 * chunk_bytes() + 8 * sizeof(PlaneEntry<W>); }
+};
+constexpr int kBitsMaxWidth32 = 31 * 64, kBitsMaxWidth64 = 63 * 64;
+
+template <typename W>
+__global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__restrict__ sel, int sel_pitch, int w, int rows,
+                                                               PlaneEntry<W> *__restrict__ planes, int nw, int chunk_rows)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    const uint32_t c = x < w ? sel[(size_t)y * sel_pitch + x] : kSelFixed; // beyond the row: fixed, non-zero
+    constexpr int UB = 8 * (int)sizeof(W) - 1, WPW = 64 / UB; // 2 words of 31 columns or 1 of 63 per wave
+    const int lane = threadIdx.x & 63, sub = lane / UB;
+    const int word = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WPW + sub;
+    const int x = word * UB + (lane - sub * UB);
+    const int y = (int)blockIdx.y - word; // blockIdx.y is the skewed row
+    // beyond the row: fixed, non-zero; beyond the image (the skew's two triangles): the same, all planes 0
+    const bool inside = sub < WPW && word < nw && x < w && y >= 0 && y < rows;
+    const uint32_t c = inside ? sel[(size_t)y * sel_pitch + x] : kSelFixed;
     const bool fixed = c & kSelFixed;
     // n_k = "this pixel is 0 when k of its two neighbours are": !t_k for a free pixel, the fixed value's
     // zero flag otherwise (the planes the resolver selects from with the upper neighbour's flags)
     const bool zf = fixed && (c & kSelZero);
-    const unsigned long long n0 = __ballot(fixed ? zf : !(c & 1)), n1 = __ballot(fixed ? zf : !(c & 2)),
-                             n2 = __ballot(fixed ? zf : !(c & 4));
-    if ((threadIdx.x & 63) == 0 && (x >> 6) < nwp) {
-        unsigned long long *row = planes + (size_t)y * 3 * nwp + (x >> 6);
-        row[0] = n0; row[nwp] = n1; row[2 * nwp] = n2;
+    const unsigned long long b0 = __ballot(fixed ? zf : !(c & 1)), b1 = __ballot(fixed ? zf : !(c & 2)),
+                             b2 = __ballot(fixed ? zf : !(c & 4));
+    if (sub < WPW && lane == sub * UB && word < nw) {
+        const W mask = (W)(~(W)0) >> 1;
+        const W n0 = (W)(b0 >> (sub * UB)) & mask;
+        const W n1 = ((W)(b1 >> (sub * UB)) & mask) | n0; // t_0 >= t_1 >= t_2, spelled out: the resolver's
+        const W n2 = ((W)(b2 >> (sub * UB)) & mask) | n1; // generate is n0 without "& n1"
+        const int chunk = blockIdx.y / chunk_rows, r = blockIdx.y - chunk * chunk_rows;
+        planes[((size_t)chunk * nw + word) * (chunk_rows + 1) + r] = PlaneEntry<W>{n0, n1, n2, 0};
     }
 }
 
-__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const unsigned long long *__restrict__ planes, int nwp,
-                                                                    int rows, unsigned long long *__restrict__ zplane,
-                                                                    int chunk_rows)
+// (s0 & s1) | (~s0 & s2) in one instruction (the compiler splits the pattern once ~s0 has a second use)
+__device__ __forceinline__ uint32_t bfi(uint32_t s0, uint32_t s1, uint32_t s2)
+{
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2));
+    return d;
+}
+__device__ __forceinline__ unsigned long long bfi(unsigned long long s0, unsigned long long s1, unsigned long long s2)
+{
+    return ((unsigned long long)bfi((uint32_t)(s0 >> 32), (uint32_t)(s1 >> 32), (uint32_t)(s2 >> 32)) << 32) |
+           bfi((uint32_t)s0, (uint32_t)s1, (uint32_t)s2);
+}
+
+// Four plane entries (four steps of one lane) from LDS, issued where they are written and waited for where
+// they are used: the compiler gathers plain LDS reads in front of one s_waitcnt, which puts the LDS latency
+// back on the chain.  LDS returns in order, so "at most the four younger entries still in flight" means
+// these have arrived; the wait takes the registers as in/out operands so that no use can move in front of it.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <typename W> struct PlaneRegs4;
+template <> struct PlaneRegs4<uint32_t> {
+    u32x4 e[4];
+    __device__ __forceinline__ void read(uint32_t addr)
+    {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                     "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                     : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                     : "v"(addr));
+    }
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])); }
+    __device__ __forceinline__ uint32_t n0(int i) const { return e[i].x; }
+    __device__ __forceinline__ uint32_t n1(int i) const { return e[i].y; }
+    __device__ __forceinline__ uint32_t n2(int i) const { return e[i].z; }
+};
+template <> struct PlaneRegs4<unsigned long long> {
+    u32x4 a[4];
+    u32x2 b[4];
+    __device__ __forceinline__ void read(uint32_t addr)
+    {
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b64 %4, %8 offset:16\n\t"
+                     "ds_read_b128 %1, %8 offset:32\n\tds_read_b64 %5, %8 offset:48\n\t"
+                     "ds_read_b128 %2, %8 offset:64\n\tds_read_b64 %6, %8 offset:80\n\t"
+                     "ds_read_b128 %3, %8 offset:96\n\tds_read_b64 %7, %8 offset:112"
+                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                     : "v"(addr));
+    }
+    __device__ __forceinline__ void arrived()
+    {
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    }
+    __device__ __forceinline__ unsigned long long n0(int i) const { return ((unsigned long long)a[i].y << 32) | a[i].x; }
+    __device__ __forceinline__ unsigned long long n1(int i) const { return ((unsigned long long)a[i].w << 32) | a[i].z; }
+    __device__ __forceinline__ unsigned long long n2(int i) const { return ((unsigned long long)b[i].y << 32) | b[i].x; }
+};
+
+template <typename W>
+__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneEntry<W> *__restrict__ planes, int nw,
+                                                                    int nchunks, W *__restrict__ zplane, int chunk_rows)
 {
     typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
     typedef __attribute__((address_space(1))) const void glb_void;
+    constexpr int UB = 8 * (int)sizeof(W) - 1, E = (int)sizeof(PlaneEntry<W>);
     extern __shared__ uint4 ws_smem4[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
     const int lane = threadIdx.x;
-    const int row_bytes = 3 * nwp * 8; // nwp is even: a multiple of 16 bytes
-    const int chunk_bytes = chunk_rows * row_bytes;
-    const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+    const int lane_bytes = (chunk_rows + 1) * E; // one word's entries of a chunk (+ the odd one)
+    const int chunk_bytes = nw * lane_bytes;     // a multiple of 16
     const uint8_t *src0 = reinterpret_cast<const uint8_t *>(planes);
     for (int o = lane * 16; o < chunk_bytes; o += 1024)
         __builtin_amdgcn_global_load_lds((glb_void *)(src0 + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
-    unsigned long long zprev = 0;
-    // Branch-free rows: lanes beyond the image's words read a zeroed quadword behind the two chunks
-    // with stride 0 and store to a scratch quadword behind the resolved plane.
-    const bool active = lane < nwp;
-    unsigned long long *zero_q = reinterpret_cast<unsigned long long *>(lds + 2 * chunk_bytes);
-    if (lane == 0) zero_q[0] = 0ull;
-    const int lstride = active ? 3 * nwp : 0; // in quadwords
-    unsigned long long *zp = active ? zplane + lane : zplane + (size_t)rows * nwp;
-    const int zstride = active ? nwp : 0;
-    // this lane's bit in a 64-bit scalar mask, as two halves
-    const uint32_t mlo = lane < 32 ? 1u << lane : 0u, mhi = lane >= 32 ? 1u << (lane - 32) : 0u;
+    W zprev = 0;
+    uint32_t cflag = 0;
+    // Branch-free steps: lanes beyond the image's words read zeroed entries behind the two chunks (so they
+    // produce no carry) and store to scratch words behind the resolved plane.
+    const bool active = lane < nw;
+    if (lane < 8 * E / 16) reinterpret_cast<uint4 *>(lds + 2 * chunk_bytes)[lane] = make_uint4(0, 0, 0, 0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const uint32_t rstep = active ? 4u * E : 0u;
+    const int z_pitch = nchunks * chunk_rows;
+    W *zp = active ? zplane + (size_t)lane * z_pitch : zplane + (size_t)nw * z_pitch;
+    const int zstep = active ? 4 : 0;
     for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint8_t *cur = lds + (c & 1) * chunk_bytes;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the chunk is there (and the zero entries)
         if (c + 1 < nchunks) {
             const uint8_t *src = src0 + (size_t)(c + 1) * chunk_bytes;
             uint8_t *dst = lds + ((c + 1) & 1) * chunk_bytes;
             for (int o = lane * 16; o < chunk_bytes; o += 1024)
                 __builtin_amdgcn_global_load_lds((glb_void *)(src + o), (lds_void *)(dst + (o - lane * 16)), 16, 0, 0);
         }
-        const int y_end = min((c + 1) * chunk_rows, rows);
-        const unsigned long long *row = active ? reinterpret_cast<const unsigned long long *>(cur) + lane : zero_q;
-        const int off_b = active ? nwp : 0, off_c = active ? 2 * nwp : 0;
-        // the next row's planes are read ahead of the chain through zprev (the row after a chunk's last
-        // one is read too, and dropped: it is inside the other chunk or the zero quadword's padding)
-        unsigned long long a = row[0], b = row[off_b], cc = row[off_c];
-        for (int y = c * chunk_rows; y < y_end; ++y) {
-            row += lstride;
-            const unsigned long long na = row[0], nb = row[off_b], nc = row[off_c];
-            // zero when the left neighbour is not / is zero, given the upper neighbour's flag
-            const unsigned long long n0 = (a & ~zprev) | (b & zprev), n1 = (b & ~zprev) | (cc & zprev);
-            // generate = n0 & n1, propagate = n1 & ~n0: the adder's operands are A = g | p = n1, B = g
-            const unsigned long long A = n1, B = n0 & n1, S0 = A + B;
-            // carries between the lanes' words: the same adder on the ballots (scalar unit)
-            const unsigned long long gw = __builtin_amdgcn_ballot_w64(S0 < A), fw = __builtin_amdgcn_ballot_w64(S0 == ~0ull);
-            const unsigned long long aw = gw | fw, sw = aw + gw, cw = sw ^ aw ^ gw; // bit l = carry into lane l
-            const bool cin = (((uint32_t)cw & mlo) | ((uint32_t)(cw >> 32) & mhi)) != 0; // column 0 of the row: no left neighbour
-            const unsigned long long S = S0 + (cin ? 1ull : 0ull);
-            const unsigned long long carries = S ^ A ^ B; // bit k = carry into column k
-            const bool cout = S0 < A || (cin && S0 == ~0ull);
-            const unsigned long long z = (carries >> 1) | (cout ? 1ull << 63 : 0ull);
-            *zp = z;
-            zp += zstride;
-            zprev = z;
-            a = na; b = nb; cc = nc;
+        uint32_t row = active ? lds0 + (uint32_t)((c & 1) * chunk_bytes + lane * lane_bytes) : lds0 + (uint32_t)(2 * chunk_bytes);
+        asm("" : "+v"(row)); // a running address, one addition per four steps, not re-derived from the base
+        // Entries are read four steps ahead of the chain through zprev (the four read behind a word's last
+        // one are dropped: they are the next word's, the other chunk's or the zero entries).
+        PlaneRegs4<W> pa, pb;
+        pa.read(row);
+        auto step4 = [&](PlaneRegs4<W> &p) {
+            p.arrived();
+            W z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // the carry out of the word to the left, one step ago: the same image row (lane 0: none)
+                const uint32_t cin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cflag, 0x138, 0xf, 0xf, true);
+                // zero when the left neighbour is not / is zero, given the upper neighbour's flag:
+                // B = generate, A = generate | propagate (n0 is inside n1: the planes kernel saw to it)
+                const W B = bfi(zprev, p.n1(i), p.n0(i)), A = bfi(zprev, p.n2(i), p.n1(i));
+                const W S = A + B + cin;
+                cflag = (uint32_t)(S >> UB);
+                // S ^ A ^ B: bit k = carry into column k = "the left neighbour is zero"; the carry out of
+                // column k: the pixel is zero
+                z[i] = B | (A & (S ^ A ^ B));
+                zprev = z[i];
+            }
+            if constexpr (sizeof(W) == 4) {
+                *reinterpret_cast<uint4 *>(zp) = make_uint4(z[0], z[1], z[2], z[3]);
+            } else {
+                reinterpret_cast<ulonglong2 *>(zp)[0] = make_ulonglong2(z[0], z[1]);
+                reinterpret_cast<ulonglong2 *>(zp)[1] = make_ulonglong2(z[2], z[3]);
+            }
+            zp += zstep;
+        };
+        for (int t = 0; t < chunk_rows; t += 8) { // chunk_rows is a multiple of 8
+            row += rstep; pb.read(row);
+            step4(pa);
+            row += rstep; pa.read(row);
+            step4(pb);
         }
     }
 }
 
+template <typename W>
 __global__ void __launch_bounds__(256) ws_smooth_apply_kernel(float *out, int out_pitch, int w, int rows,
                                                               const uint8_t *__restrict__ sel, int sel_pitch,
-                                                              const unsigned long long *__restrict__ zplane, int nwp)
+                                                              const W *__restrict__ zplane, int z_pitch)
 {
+    constexpr int UB = 8 * (int)sizeof(W) - 1;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w || y >= rows) return;
     if (sel[(size_t)y * sel_pitch + x] & kSelFixed) return;
-    if ((zplane[(size_t)y * nwp + (x >> 6)] >> (x & 63)) & 1ull) out[(size_t)y * out_pitch + x] = 0.0f;
+    const int word = x / UB;
+    if ((zplane[(size_t)word * z_pitch + y + word] >> (x - word * UB)) & 1) out[(size_t)y * out_pitch + x] = 0.0f; // skewed rows
+}
+
+template <typename W>
+static hipError_t launch_smooth_bits(const GenericArgs &g, const uint8_t *sel, int sel_pitch, unsigned long long *buf, int rows,
+                                     hipStream_t st)
+{
+    const BitsLayout<W> lay(g.w2, rows);
+    constexpr int words_per_block = 4 * (64 / BitsLayout<W>::kBits);
+    PlaneEntry<W> *planes = reinterpret_cast<PlaneEntry<W> *>(buf);
+    W *zplane = reinterpret_cast<W *>(planes + lay.plane_entries);
+    hipLaunchKernelGGL(ws_smooth_planes_kernel<W>, dim3(ceil_div(lay.nw, words_per_block), lay.nchunks * lay.chunk_rows), dim3(256),
+                       0, st, sel, sel_pitch, g.w2, rows, planes, lay.nw, lay.chunk_rows);
+    hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel<W>, dim3(1), dim3(64), lay.lds_bytes(), st, planes, lay.nw, lay.nchunks,
+                       zplane, lay.chunk_rows);
+    hipLaunchKernelGGL(ws_smooth_apply_kernel<W>, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch, g.w2, rows,
+                       sel, sel_pitch, zplane, lay.z_pitch());
+    return hipGetLastError();
 }
 
 int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
 
 size_t smooth_planes_bytes(int w, int h)
 {
-    const int nwp = round_up(ceil_div(w, 64), 2);
-    return (size_t)(h + 64) * 4 * nwp * 8; // 3 code planes + the resolved plane
+    if (w <= kBitsMaxWidth32) return BitsLayout<uint32_t>(w, h).bytes();
+    if (w <= kBitsMaxWidth64) return BitsLayout<unsigned long long>(w, h).bytes();
+    return 64; // wider images take the other resolvers
 }
 
 hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_pitch, unsigned long long *planes,
@@ -1291,21 +1420,9 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int rows = std::min(g.h1, g.h2);
-    const int nwords = ceil_div(g.w2, 64);
-    if (s >= 0.0 && s <= 1.0 && nwords <= 64 && planes) {
-        const int nwp = round_up(nwords, 2);
-        unsigned long long *zplane = planes + (size_t)(g.h2 + 64) * 3 * nwp;
-        hipLaunchKernelGGL(ws_smooth_planes_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, sel, sel_pitch,
-                           g.w2, planes, nwp);
-        int chunk = 24576 / (3 * nwp * 8);
-        if (chunk > 64) chunk = 64;
-        if (chunk < 1) chunk = 1;
-        hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel, dim3(1), dim3(64), (size_t)2 * chunk * 3 * nwp * 8 + 3 * nwp * 8 + 64, st, planes,
-                           nwp, rows, zplane, chunk);
-        hipLaunchKernelGGL(ws_smooth_apply_kernel, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch,
-                           g.w2, rows, sel, sel_pitch, zplane, nwp);
-        return hipGetLastError();
-    }
+    if (s >= 0.0 && s <= 1.0 && planes && g.w2 <= kBitsMaxWidth64)
+        return g.w2 <= kBitsMaxWidth32 ? launch_smooth_bits<uint32_t>(g, sel, sel_pitch, planes, rows, st)
+                                       : launch_smooth_bits<unsigned long long>(g, sel, sel_pitch, planes, rows, st);
     const int per = ceil_div(g.w2, 64);
     // rows per LDS chunk: two chunks in at most 64 KB, a multiple of 16 rows (whole 1 KB DMA pieces)
     int chunk = (32768 / sel_pitch) / 16 * 16;
