@@ -38,6 +38,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PROFILE_ROUND = "r02"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
 
+# A step is one pass of the hot path over one BATCH of pairs of the workload's shape (distinct images), so that
+# the few steps the driver times (20 after 5 of warm-up) are tens of milliseconds of device work: a 0.17 ms
+# pair timed 25 times in a row measures the clocks coming up, not the path (measured: 2.18e6 Mdisparities/s
+# over 5 + 50 single pairs, 2.33e6 over 50 + 200 and over 200 + 1000).
+PAIRS_PER_STEP = {"config2": 16, "config3": 4, "config5": 2, "config1": 64}
 WORKLOADS = {
     # name: (width, height, block, cost, maxD, seed)
     "config2": (1500, 1000, 7, "ssd", 256, 2),
@@ -72,6 +77,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-rows", type=int, default=1000,
                     help="rows of the all-cores CPU baseline sample (1/16 of it for the one-core sample)")
     ap.add_argument("--check", action="store_true", help="compare a row band with the oracle")
+    ap.add_argument("--pairs-per-step", type=int, default=0,
+                    help="pairs a rank searches per step (its batch); 0 = the workload's default")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="contexts (own stream + scratch each) a rank's batch alternates over: with 2, one pair's "
+                         "pre-pass and launch gaps run beside the other pair's search")
     return ap.parse_args(argv)
 
 
@@ -148,8 +158,9 @@ def main():
         if dist is not None:
             dist.barrier()
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
-    ctx = None if dry else ws.WindowSearch(local_rank)
-    stream = None if dry else torch.cuda.current_stream().cuda_stream
+    in_flight = max(1, args.in_flight)
+    ctxs = [] if dry else [ws.WindowSearch(local_rank) for _ in range(in_flight)]
+    ctx = ctxs[0] if ctxs else None
     batch = args.workload == "config4"
     if batch:
         from stereo_reconstruction_amd.sharding import lpt_assign
@@ -160,29 +171,40 @@ def main():
         todo = [(shapes[i][0], shapes[i][1], 100 + i) for i in mine]
         hyps_total = float(sum(w * h * max_d for w, h in shapes))
         width, height = shapes[0]
+        pps = 0
     else:
         width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
-        mine = [rank]
-        todo = [(width, height, seed + rank)]
-        hyps_total = float(width) * height * max_d * world   # one pair per rank (weak scaling)
+        pps = args.pairs_per_step if args.pairs_per_step > 0 else PAIRS_PER_STEP[args.workload]
+        mine = [rank * pps + i for i in range(pps)]
+        todo = [(width, height, seed + rank)] * pps
+        hyps_total = float(width) * height * max_d * pps * world   # the same batch per rank (weak scaling)
     host_pairs, pairs = [], []
-    for w, h, sd in todo:
+    made = {}
+    for k, (w, h, sd) in enumerate(todo):
         if dry:
             host_pairs.append((None, None))
             pairs.append((w, h))
             continue
-        l, r, _ = make_pair(w, h, max_d, sd)
-        host_pairs.append((l, r))
-        pairs.append((torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev),
-                      torch.empty((h, w), dtype=torch.float32, device=dev)))
+        if (w, h, sd) not in made:
+            l, r, _ = make_pair(w, h, max_d, sd)
+            made[(w, h, sd)] = (l, r, torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev))
+            host_pairs.append((l, r))
+            tl, tr = made[(w, h, sd)][2:]
+        else:
+            # further pairs of the batch: the same scene shifted down by a few rows (both views alike, so it
+            # still is a rectified pair) -- different bytes in every buffer without a second of numpy per pair
+            tl, tr = (torch.roll(t, 37 * k, 0).contiguous() for t in made[(w, h, sd)][2:])
+        pairs.append((tl, tr, torch.empty((h, w), dtype=torch.float32, device=dev)))
     params = None if dry else ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
 
     def step():
         if dry:
-            time.sleep(1e-3 * len(pairs))
+            time.sleep(1e-4 * len(pairs))
             return
-        for tl, tr, to in pairs:   # whole pairs per rank, no collective on the data path
-            ctx.search_device(params, tl, tr, to, stream)
+        # whole pairs per rank, no collective on the data path; consecutive pairs on alternating contexts
+        # (each on its own stream, with its own scratch planes)
+        for k, (tl, tr, to) in enumerate(pairs):
+            ctxs[k % in_flight].search_device(params, tl, tr, to, None)
 
     def sync():
         if not dry:
@@ -217,7 +239,7 @@ def main():
         ctx.set_profiling(True)
         for _ in range(reps):
             for i, (tl, tr, to) in enumerate(pairs):
-                ctx.search_device(params, tl, tr, to, stream)
+                ctx.search_device(params, tl, tr, to, None)   # one pair at a time: the kernel alone on the device
                 kernel_ms[i] += ctx.last_kernel_ms() / reps
         ctx.set_profiling(False)
         info = ctx.last_launch()
@@ -271,9 +293,10 @@ def main():
                                    if rehearse else ""),
             "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
                                     "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
-                                   "%s: one %dx%d BGR pair per GPU, left view, %dx%d %s, D=%d, smoothFactor 1.0"
-                                   % (args.workload, width, height, bs, bs, cost.upper(), max_d),
-                       "pairs_per_step": 15 if batch else world, "sharding": "independent pairs, no collective"},
+                                   "%s: a batch of %d %dx%d BGR pairs per GPU and step, left view, %dx%d %s, D=%d, smoothFactor 1.0"
+                                   % (args.workload, pps, width, height, bs, bs, cost.upper(), max_d),
+                       "pairs_per_step": 15 if batch else pps * world, "in_flight_per_gpu": in_flight,
+                       "sharding": "independent pairs, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": info["kernel"], "kernel_ms": round(k_ms / n_launch, 4),

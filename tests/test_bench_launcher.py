@@ -30,7 +30,9 @@ def test_self_launch_two_ranks_weak_scaling():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert out["config"]["pairs_per_step"] == 2
+    # a batch of 16 config-2 pairs per rank and step (bench.PAIRS_PER_STEP), alternating over two contexts
+    assert out["config"]["pairs_per_step"] == 32 and out["config"]["in_flight_per_gpu"] == 2
+    assert [r["pairs"] for r in out["per_rank"]] == [16, 16]
     assert [r["rank"] for r in out["per_rank"]] == [0, 1]
     assert out["value"] > 0 and "REHEARSAL" in out["data"]
 
