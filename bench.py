@@ -9,16 +9,18 @@ process only launches the N ranks (fresh child processes, before anything here t
 waits for them and passes rank 0's JSON line through.
 
 A "step" is one pass of the hot path (BlockSearch::computeDisparityMapLeft,
-BlockSearch.cpp:24-86, through the C-ABI ws_search_device) over one synthetic
-Middlebury-H-shaped pair that is already resident in HBM: BASELINE.json configs[1]
-= 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0.  With N ranks every rank
-owns its own pair (independent pairs shard with no collective: weak scaling); the
-barrier / all_reduce(MAX) below only brackets the timing.  `--workload config4` is
+BlockSearch.cpp:24-86, through the C-ABI ws_search_device) over one BATCH of synthetic
+Middlebury-H-shaped pairs already resident in HBM: BASELINE.json configs[1]
+= 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0, 16 pairs per step (so that the
+few steps the driver times are tens of milliseconds of work), consecutive pairs on
+alternating contexts (--in-flight 2: one pair's pre-pass overlaps the other's search).
+With N ranks every rank owns its own batch (independent pairs shard with no collective:
+weak scaling); the barrier / all_reduce(MAX) below only brackets the timing.  `--workload config4` is
 BASELINE.json configs[3]: the 15 trainingH-shaped pairs sharded over the ranks (strong).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
 (ws_march_kernel): algorithmic bytes per launch / its average duration measured
-with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
+with HIP events on the launch stream, one pair at a time (the kernel alone on the device).  `cpu_baseline` times the CPU oracle
 (oracle/, a port: the reference itself cannot be built here) on a bounded row band
 of the same workload on this box's host cores, all cores and one core (the reference
 is single-threaded).  `e2e` is what a caller of the boundary gets from ONE
