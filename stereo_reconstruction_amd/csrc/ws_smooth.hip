@@ -1150,8 +1150,9 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
 // There c0 * s^k does not grow with k, so t_0 >= t_1 >= t_2 and a pixel is one of: always 0
 // ("generate"), never 0 ("kill"), or 0 exactly when its left neighbour is ("propagate") -- a
 // carry chain.  With the codes packed into bit planes one lane resolves a word of columns with a
-// single addition (A = g|p, B = g: the carries of A+B are the chain).  Words hold 31 (63 for
-// images wider than 1984) columns, so the carry out of a word is the top bit of the sum.
+// single addition (A = g|p, B = g: the carries of A+B are the chain).  Words hold 31 columns,
+// so the carry out of a word is the top bit of the sum; a lane takes one word, or two for
+// images wider than 1984 (3968 at most; wider ones go to the other resolvers).
 // The words of a row are skewed in time: lane l works on row t - l at step t, so the carry into
 // its word is what lane l-1 produced one step earlier (one DPP shift) and the flags of the row
 // above are its own previous result -- a systolic array in one wave, no scalar unit, no ballots.
@@ -1159,42 +1160,49 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
 // instructions: 6 of arithmetic, one LDS read, and a wait / store / address update per 4 steps.
 // The planes are stored the way the lanes walk them: per LDS chunk, per word, the skewed rows
 // (word l of image row y is skewed row y + l) one entry after the other.
-template <typename W> struct alignas(4 * sizeof(W)) PlaneEntry { W n0, n1, n2, pad; }; // one LDS read (b128) or two
+template <int NS> struct alignas(16) PlaneEntry { uint32_t v[NS][4]; }; // per sub-word: n0, n1, n2, padding (one b128 LDS read)
 
-template <typename W> struct BitsLayout {
-    static constexpr int kBits = 8 * (int)sizeof(W) - 1; // columns per word
+// NS = 31-column sub-words per lane: 1, or 2 for images wider than 1984 (the second one takes the first one's
+// carry in the same step: 4 more instructions a step, against 64-bit adds at a quarter of the rate).
+template <int NS> struct BitsLayout {
+    static constexpr int kBits = 31 * NS; // columns per lane
     int nw, steps, chunk_rows, nchunks;
     size_t plane_entries, z_words;
     __host__ BitsLayout(int w, int rows)
     {
         nw = ceil_div(w, kBits);
         steps = round_up(rows + nw, 8);
-        // two chunks of (chunk_rows + 1) entries per word in ~48 KB of LDS; the odd entry keeps the lanes on different banks
-        chunk_rows = (int)(24576 / ((size_t)nw * sizeof(PlaneEntry<W>)) - 1) / 8 * 8;
+        // two chunks of chunk_rows entries (+ 16 bytes) per lane in ~128 KB of LDS; the odd 16 bytes keep the
+        // lanes' b128 reads on different banks (an even stride in 16-byte units: 8 lanes per bank group, measured
+        // 118 instead of 60 ns a step at two sub-words per lane)
+        chunk_rows = (int)((65536 - 16 * (size_t)nw) / ((size_t)nw * sizeof(PlaneEntry<NS>))) / 8 * 8;
         if (chunk_rows > 64) chunk_rows = 64;
         if (chunk_rows < 8) chunk_rows = 8;
         nchunks = ceil_div(steps, chunk_rows);
-        plane_entries = (size_t)nchunks * nw * (chunk_rows + 1);
-        z_words = (size_t)nw * nchunks * chunk_rows + 8; // + the idle lanes' scratch
+        plane_entries = ((size_t)nchunks * nw * lane_bytes() + sizeof(PlaneEntry<NS>) - 1) / sizeof(PlaneEntry<NS>);
+        z_words = ((size_t)nw * nchunks * chunk_rows + 8) * NS; // + the idle lanes' scratch
     }
     __host__ int z_pitch() const { return nchunks * chunk_rows; }
-    __host__ size_t bytes() const { return plane_entries * sizeof(PlaneEntry<W>) + z_words * sizeof(W) + 64; }
-    __host__ size_t chunk_bytes() const { return (size_t)nw * (chunk_rows + 1) * sizeof(PlaneEntry<W>); }
-    __host__ size_t lds_bytes() const { return 2 * chunk_bytes() + 8 * sizeof(PlaneEntry<W>); }
+    __host__ size_t lane_bytes() const { return (size_t)chunk_rows * sizeof(PlaneEntry<NS>) + 16; }
+    __host__ size_t bytes() const { return plane_entries * sizeof(PlaneEntry<NS>) + z_words * 4 + 64; }
+    __host__ size_t chunk_bytes() const { return (size_t)nw * lane_bytes(); }
+    __host__ size_t lds_bytes() const { return 2 * chunk_bytes() + 8 * sizeof(PlaneEntry<NS>); }
 };
-constexpr int kBitsMaxWidth32 = 31 * 64, kBitsMaxWidth64 = 63 * 64;
+constexpr int kBitsMaxWidth1 = 31 * 64, kBitsMaxWidth2 = 62 * 64;
 
-template <typename W>
+template <int NS>
 __global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__restrict__ sel, int sel_pitch, int w, int rows,
-                                                               PlaneEntry<W> *__restrict__ planes, int nw, int chunk_rows)
+                                                               PlaneEntry<NS> *__restrict__ planes, int nw, int chunk_rows)
 {
-    constexpr int UB = 8 * (int)sizeof(W) - 1, WPW = 64 / UB; // 2 words of 31 columns or 1 of 63 per wave
-    const int lane = threadIdx.x & 63, sub = lane / UB;
-    const int word = (blockIdx.x * 4 + (threadIdx.x >> 6)) * WPW + sub;
-    const int x = word * UB + (lane - sub * UB);
+    // a wave takes 62 columns = two sub-words (lanes 0..30 and 31..61): two lanes' words, of two image rows
+    // (NS = 1), or the two halves of one lane's word (NS = 2)
+    const int lane = threadIdx.x & 63, sub = lane / 31;
+    const int gsw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + sub; // sub-word of the row
+    const int word = gsw / NS;                                       // = the lane that resolves it
+    const int x = gsw * 31 + (lane - sub * 31);
     const int y = (int)blockIdx.y - word; // blockIdx.y is the skewed row
     // beyond the row: fixed, non-zero; beyond the image (the skew's two triangles): the same, all planes 0
-    const bool inside = sub < WPW && word < nw && x < w && y >= 0 && y < rows;
+    const bool inside = sub < 2 && word < nw && x < w && y >= 0 && y < rows;
     const uint32_t c = inside ? sel[(size_t)y * sel_pitch + x] : kSelFixed;
     const bool fixed = c & kSelFixed;
     // n_k = "this pixel is 0 when k of its two neighbours are": !t_k for a free pixel, the fixed value's
@@ -1202,13 +1210,17 @@ __global__ void __launch_bounds__(256) ws_smooth_planes_kernel(const uint8_t *__
     const bool zf = fixed && (c & kSelZero);
     const unsigned long long b0 = __ballot(fixed ? zf : !(c & 1)), b1 = __ballot(fixed ? zf : !(c & 2)),
                              b2 = __ballot(fixed ? zf : !(c & 4));
-    if (sub < WPW && lane == sub * UB && word < nw) {
-        const W mask = (W)(~(W)0) >> 1;
-        const W n0 = (W)(b0 >> (sub * UB)) & mask;
-        const W n1 = ((W)(b1 >> (sub * UB)) & mask) | n0; // t_0 >= t_1 >= t_2, spelled out: the resolver's
-        const W n2 = ((W)(b2 >> (sub * UB)) & mask) | n1; // generate is n0 without "& n1"
+    if (sub < 2 && lane == sub * 31 && word < nw) {
+        const uint32_t mask = 0x7fffffffu;
+        const uint32_t n0 = (uint32_t)(b0 >> (sub * 31)) & mask;
+        const uint32_t n1 = ((uint32_t)(b1 >> (sub * 31)) & mask) | n0; // t_0 >= t_1 >= t_2, spelled out: the resolver's
+        const uint32_t n2 = ((uint32_t)(b2 >> (sub * 31)) & mask) | n1; // generate is n0 without "& n1"
         const int chunk = blockIdx.y / chunk_rows, r = blockIdx.y - chunk * chunk_rows;
-        planes[((size_t)chunk * nw + word) * (chunk_rows + 1) + r] = PlaneEntry<W>{n0, n1, n2, 0};
+        // per chunk and lane: chunk_rows entries + 16 bytes (see BitsLayout)
+        const size_t lane_bytes = (size_t)chunk_rows * sizeof(PlaneEntry<NS>) + 16;
+        uint8_t *q = reinterpret_cast<uint8_t *>(planes) + ((size_t)chunk * nw + word) * lane_bytes +
+                     ((size_t)r * NS + (gsw - word * NS)) * 16;
+        *reinterpret_cast<uint4 *>(q) = make_uint4(n0, n1, n2, 0u);
     }
 }
 
@@ -1219,10 +1231,15 @@ __device__ __forceinline__ uint32_t bfi(uint32_t s0, uint32_t s1, uint32_t s2)
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2));
     return d;
 }
-__device__ __forceinline__ unsigned long long bfi(unsigned long long s0, unsigned long long s1, unsigned long long s2)
+
+// B | (A & (S ^ A ^ B)) -- the carry out of every column of S = A + B + carry-in -- as one three-input bit
+// operation (truth table over (A, B, S), A the high index bit: 0xdc); the compiler finds it for one sub-word
+// per lane and spends three instructions on it for two.
+__device__ __forceinline__ uint32_t carry_out_bits(uint32_t A, uint32_t B, uint32_t S)
 {
-    return ((unsigned long long)bfi((uint32_t)(s0 >> 32), (uint32_t)(s1 >> 32), (uint32_t)(s2 >> 32)) << 32) |
-           bfi((uint32_t)s0, (uint32_t)s1, (uint32_t)s2);
+    uint32_t z;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xdc" : "=v"(z) : "v"(A), "v"(B), "v"(S));
+    return z;
 }
 
 // Four plane entries (four steps of one lane) from LDS, issued where they are written and waited for where
@@ -1230,61 +1247,58 @@ __device__ __forceinline__ unsigned long long bfi(unsigned long long s0, unsigne
 // back on the chain.  LDS returns in order, so "at most the four younger entries still in flight" means
 // these have arrived; the wait takes the registers as in/out operands so that no use can move in front of it.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <typename W> struct PlaneRegs4;
-template <> struct PlaneRegs4<uint32_t> {
-    u32x4 e[4];
+template <int NS> struct PlaneRegs4;
+template <> struct PlaneRegs4<1> {
+    u32x4 e[4][1];
     __device__ __forceinline__ void read(uint32_t addr)
     {
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
                      "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
-                     : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                     : "=&v"(e[0][0]), "=&v"(e[1][0]), "=&v"(e[2][0]), "=&v"(e[3][0])
                      : "v"(addr));
     }
-    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])); }
-    __device__ __forceinline__ uint32_t n0(int i) const { return e[i].x; }
-    __device__ __forceinline__ uint32_t n1(int i) const { return e[i].y; }
-    __device__ __forceinline__ uint32_t n2(int i) const { return e[i].z; }
+    __device__ __forceinline__ void arrived()
+    {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[0][0]), "+v"(e[1][0]), "+v"(e[2][0]), "+v"(e[3][0]));
+    }
 };
-template <> struct PlaneRegs4<unsigned long long> {
-    u32x4 a[4];
-    u32x2 b[4];
+template <> struct PlaneRegs4<2> {
+    u32x4 e[4][2];
     __device__ __forceinline__ void read(uint32_t addr)
     {
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b64 %4, %8 offset:16\n\t"
-                     "ds_read_b128 %1, %8 offset:32\n\tds_read_b64 %5, %8 offset:48\n\t"
-                     "ds_read_b128 %2, %8 offset:64\n\tds_read_b64 %6, %8 offset:80\n\t"
-                     "ds_read_b128 %3, %8 offset:96\n\tds_read_b64 %7, %8 offset:112"
-                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
+                     "ds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                     "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                     "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"
+                     : "=&v"(e[0][0]), "=&v"(e[0][1]), "=&v"(e[1][0]), "=&v"(e[1][1]), "=&v"(e[2][0]), "=&v"(e[2][1]),
+                       "=&v"(e[3][0]), "=&v"(e[3][1])
                      : "v"(addr));
     }
     __device__ __forceinline__ void arrived()
     {
         asm volatile("s_waitcnt lgkmcnt(8)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+                     : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[2][0]), "+v"(e[2][1]), "+v"(e[3][0]),
+                       "+v"(e[3][1]));
     }
-    __device__ __forceinline__ unsigned long long n0(int i) const { return ((unsigned long long)a[i].y << 32) | a[i].x; }
-    __device__ __forceinline__ unsigned long long n1(int i) const { return ((unsigned long long)a[i].w << 32) | a[i].z; }
-    __device__ __forceinline__ unsigned long long n2(int i) const { return ((unsigned long long)b[i].y << 32) | b[i].x; }
 };
 
-template <typename W>
-__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneEntry<W> *__restrict__ planes, int nw,
-                                                                    int nchunks, W *__restrict__ zplane, int chunk_rows)
+template <int NS>
+__global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneEntry<NS> *__restrict__ planes, int nw,
+                                                                    int nchunks, uint32_t *__restrict__ zplane, int chunk_rows)
 {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
     typedef __attribute__((address_space(1))) const void glb_void;
-    constexpr int UB = 8 * (int)sizeof(W) - 1, E = (int)sizeof(PlaneEntry<W>);
+    constexpr int E = (int)sizeof(PlaneEntry<NS>);
     extern __shared__ uint4 ws_smem4[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(ws_smem4);
     const int lane = threadIdx.x;
-    const int lane_bytes = (chunk_rows + 1) * E; // one word's entries of a chunk (+ the odd one)
+    const int lane_bytes = chunk_rows * E + 16; // one lane's entries of a chunk (+ the odd 16 bytes)
     const int chunk_bytes = nw * lane_bytes;     // a multiple of 16
     const uint8_t *src0 = reinterpret_cast<const uint8_t *>(planes);
     for (int o = lane * 16; o < chunk_bytes; o += 1024)
         __builtin_amdgcn_global_load_lds((glb_void *)(src0 + o), (lds_void *)(lds + (o - lane * 16)), 16, 0, 0);
-    W zprev = 0;
+    uint32_t zprev[NS] = {};
     uint32_t cflag = 0;
     // Branch-free steps: lanes beyond the image's words read zeroed entries behind the two chunks (so they
     // produce no carry) and store to scratch words behind the resolved plane.
@@ -1293,8 +1307,8 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneE
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8 *)lds;
     const uint32_t rstep = active ? 4u * E : 0u;
     const int z_pitch = nchunks * chunk_rows;
-    W *zp = active ? zplane + (size_t)lane * z_pitch : zplane + (size_t)nw * z_pitch;
-    const int zstep = active ? 4 : 0;
+    uint32_t *zp = zplane + (size_t)(active ? lane : nw) * z_pitch * NS;
+    const int zstep = active ? 4 * NS : 0;
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the chunk is there (and the zero entries)
         if (c + 1 < nchunks) {
@@ -1305,32 +1319,37 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneE
         }
         uint32_t row = active ? lds0 + (uint32_t)((c & 1) * chunk_bytes + lane * lane_bytes) : lds0 + (uint32_t)(2 * chunk_bytes);
         asm("" : "+v"(row)); // a running address, one addition per four steps, not re-derived from the base
-        // Entries are read four steps ahead of the chain through zprev (the four read behind a word's last
-        // one are dropped: they are the next word's, the other chunk's or the zero entries).
-        PlaneRegs4<W> pa, pb;
+        // Entries are read four steps ahead of the chain through zprev (the four read behind a lane's last
+        // one are dropped: they are the next lane's, the other chunk's or the zero entries).
+        PlaneRegs4<NS> pa, pb;
         pa.read(row);
-        auto step4 = [&](PlaneRegs4<W> &p) {
+        auto step4 = [&](PlaneRegs4<NS> &p) {
             p.arrived();
-            W z[4];
+            uint32_t z[4][NS];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // the carry out of the word to the left, one step ago: the same image row (lane 0: none)
-                const uint32_t cin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cflag, 0x138, 0xf, 0xf, true);
-                // zero when the left neighbour is not / is zero, given the upper neighbour's flag:
-                // B = generate, A = generate | propagate (n0 is inside n1: the planes kernel saw to it)
-                const W B = bfi(zprev, p.n1(i), p.n0(i)), A = bfi(zprev, p.n2(i), p.n1(i));
-                const W S = A + B + cin;
-                cflag = (uint32_t)(S >> UB);
-                // S ^ A ^ B: bit k = carry into column k = "the left neighbour is zero"; the carry out of
-                // column k: the pixel is zero
-                z[i] = B | (A & (S ^ A ^ B));
-                zprev = z[i];
+                // the carry out of the lane to the left, one step ago: the same image row (lane 0: none)
+                uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cflag, 0x138, 0xf, 0xf, true);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    // zero when the left neighbour is not / is zero, given the upper neighbour's flag:
+                    // B = generate, A = generate | propagate (n0 is inside n1: the planes kernel saw to it)
+                    const uint32_t B = bfi(zprev[k], p.e[i][k].y, p.e[i][k].x), A = bfi(zprev[k], p.e[i][k].z, p.e[i][k].y);
+                    const uint32_t S = A + B + carry;
+                    carry = S >> 31; // into the next sub-word, or the next lane's first one a step later
+                    // S ^ A ^ B: bit j = carry into column j = "the left neighbour is zero"; the carry out of
+                    // column j: the pixel is zero
+                    z[i][k] = carry_out_bits(A, B, S);
+                    zprev[k] = z[i][k];
+                }
+                cflag = carry;
             }
-            if constexpr (sizeof(W) == 4) {
-                *reinterpret_cast<uint4 *>(zp) = make_uint4(z[0], z[1], z[2], z[3]);
+            uint4 *q = reinterpret_cast<uint4 *>(zp);
+            if constexpr (NS == 1) {
+                q[0] = make_uint4(z[0][0], z[1][0], z[2][0], z[3][0]);
             } else {
-                reinterpret_cast<ulonglong2 *>(zp)[0] = make_ulonglong2(z[0], z[1]);
-                reinterpret_cast<ulonglong2 *>(zp)[1] = make_ulonglong2(z[2], z[3]);
+                q[0] = make_uint4(z[0][0], z[0][1], z[1][0], z[1][1]);
+                q[1] = make_uint4(z[2][0], z[2][1], z[3][0], z[3][1]);
             }
             zp += zstep;
         };
@@ -1343,33 +1362,37 @@ __global__ void __launch_bounds__(64) ws_smooth_resolve_bits_kernel(const PlaneE
     }
 }
 
-template <typename W>
+template <int NS>
 __global__ void __launch_bounds__(256) ws_smooth_apply_kernel(float *out, int out_pitch, int w, int rows,
                                                               const uint8_t *__restrict__ sel, int sel_pitch,
-                                                              const W *__restrict__ zplane, int z_pitch)
+                                                              const uint32_t *__restrict__ zplane, int z_pitch)
 {
-    constexpr int UB = 8 * (int)sizeof(W) - 1;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w || y >= rows) return;
     if (sel[(size_t)y * sel_pitch + x] & kSelFixed) return;
-    const int word = x / UB;
-    if ((zplane[(size_t)word * z_pitch + y + word] >> (x - word * UB)) & 1) out[(size_t)y * out_pitch + x] = 0.0f; // skewed rows
+    const int sw = x / 31, word = sw / NS; // sub-word of the row, lane that resolved it (skewed rows)
+    if ((zplane[((size_t)word * z_pitch + y + word) * NS + (sw - word * NS)] >> (x - sw * 31)) & 1)
+        out[(size_t)y * out_pitch + x] = 0.0f;
 }
 
-template <typename W>
+template <int NS>
 static hipError_t launch_smooth_bits(const GenericArgs &g, const uint8_t *sel, int sel_pitch, unsigned long long *buf, int rows,
                                      hipStream_t st)
 {
-    const BitsLayout<W> lay(g.w2, rows);
-    constexpr int words_per_block = 4 * (64 / BitsLayout<W>::kBits);
-    PlaneEntry<W> *planes = reinterpret_cast<PlaneEntry<W> *>(buf);
-    W *zplane = reinterpret_cast<W *>(planes + lay.plane_entries);
-    hipLaunchKernelGGL(ws_smooth_planes_kernel<W>, dim3(ceil_div(lay.nw, words_per_block), lay.nchunks * lay.chunk_rows), dim3(256),
-                       0, st, sel, sel_pitch, g.w2, rows, planes, lay.nw, lay.chunk_rows);
-    hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel<W>, dim3(1), dim3(64), lay.lds_bytes(), st, planes, lay.nw, lay.nchunks,
+    const BitsLayout<NS> lay(g.w2, rows);
+    PlaneEntry<NS> *planes = reinterpret_cast<PlaneEntry<NS> *>(buf);
+    uint32_t *zplane = reinterpret_cast<uint32_t *>(planes + lay.plane_entries);
+    hipLaunchKernelGGL(ws_smooth_planes_kernel<NS>, dim3(ceil_div(lay.nw * NS, 8), lay.nchunks * lay.chunk_rows), dim3(256), 0, st,
+                       sel, sel_pitch, g.w2, rows, planes, lay.nw, lay.chunk_rows);
+    if (lay.lds_bytes() > 48 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(ws_smooth_resolve_bits_kernel<NS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.lds_bytes());
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(ws_smooth_resolve_bits_kernel<NS>, dim3(1), dim3(64), lay.lds_bytes(), st, planes, lay.nw, lay.nchunks,
                        zplane, lay.chunk_rows);
-    hipLaunchKernelGGL(ws_smooth_apply_kernel<W>, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch, g.w2, rows,
+    hipLaunchKernelGGL(ws_smooth_apply_kernel<NS>, dim3(ceil_div(g.w2, 256), rows), dim3(256), 0, st, g.out, g.out_pitch, g.w2, rows,
                        sel, sel_pitch, zplane, lay.z_pitch());
     return hipGetLastError();
 }
@@ -1378,8 +1401,8 @@ int smooth_sel_rows(int rows) { return (rows + 15) / 16 * 16 + 16; }
 
 size_t smooth_planes_bytes(int w, int h)
 {
-    if (w <= kBitsMaxWidth32) return BitsLayout<uint32_t>(w, h).bytes();
-    if (w <= kBitsMaxWidth64) return BitsLayout<unsigned long long>(w, h).bytes();
+    if (w <= kBitsMaxWidth1) return BitsLayout<1>(w, h).bytes();
+    if (w <= kBitsMaxWidth2) return BitsLayout<2>(w, h).bytes();
     return 64; // wider images take the other resolvers
 }
 
@@ -1420,9 +1443,9 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int rows = std::min(g.h1, g.h2);
-    if (s >= 0.0 && s <= 1.0 && planes && g.w2 <= kBitsMaxWidth64)
-        return g.w2 <= kBitsMaxWidth32 ? launch_smooth_bits<uint32_t>(g, sel, sel_pitch, planes, rows, st)
-                                       : launch_smooth_bits<unsigned long long>(g, sel, sel_pitch, planes, rows, st);
+    if (s >= 0.0 && s <= 1.0 && planes && g.w2 <= kBitsMaxWidth2)
+        return g.w2 <= kBitsMaxWidth1 ? launch_smooth_bits<1>(g, sel, sel_pitch, planes, rows, st)
+                                      : launch_smooth_bits<2>(g, sel, sel_pitch, planes, rows, st);
     const int per = ceil_div(g.w2, 64);
     // rows per LDS chunk: two chunks in at most 64 KB, a multiple of 16 rows (whole 1 KB DMA pieces)
     int chunk = (32768 / sel_pitch) / 16 * 16;

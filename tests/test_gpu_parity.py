@@ -176,6 +176,28 @@ def test_smooth_factor_right_view_and_linear(wslib, gpu_ctx, oracle, smooth, lev
     assert np.array_equal(got, oracle.linear(left, right, smooth=smooth))
 
 
+@pytest.mark.parametrize("width", [31, 62, 63, 1984, 1985, 2500, 3968, 3969])
+def test_smooth_factor_right_view_word_layouts(wslib, gpu_ctx, oracle, width):
+    """The right view's 0 <= smoothFactor <= 1 resolver packs 31 columns per word, one word per lane up to
+    1984 columns, two up to 3968, the other resolvers beyond (ws_smooth.hip): widths on both sides of every
+    limit, few levels so that zeros spread over long runs and whole rows (carries through every word and lane),
+    and LinearSearch, which shares the resolver."""
+    rng = np.random.default_rng(width)
+    h = 24 if width > 1000 else 150          # the tall narrow ones cross several LDS chunks of skewed rows
+    left = (rng.integers(0, 2, size=(h, width, 3)) * 255).astype(np.uint8)
+    right = left.copy()
+    right[rng.random((h, width)) < 0.02] = 255   # mostly equal images: d = 0 wins or ties almost everywhere
+    left[3:6, :] = right[3:6, :] = 0             # whole rows of exact ties
+    for bs, maxd, smooth, cost in ((5, 6, 0.9, "ssd"), (3, 4, 0.5, "sad")):
+        got = wslib.BlockSearch(left, right, bs, 0, maxd, cost=cost, context=gpu_ctx).computeDisparityMapRight(smooth)
+        want = oracle.block_right(left, right, bs, 0, maxd, smooth=smooth, cost=cost, threads=8)
+        assert np.array_equal(got, want), (width, bs, smooth)
+        assert (got == 0).mean() > 0.3
+    if width <= 2500:
+        got = wslib.LinearSearch(left, right, context=gpu_ctx, search_range=12).computeDisparityMap(0.5)
+        assert np.array_equal(got, oracle.linear(left, right, smooth=0.5, search_range=12))
+
+
 @pytest.mark.parametrize("smooth", [0.9, 0.5, 0.0, 1.3, 4.0, -0.5, -2.0, float("inf")])
 @pytest.mark.parametrize("levels", [256, 3, 2])
 def test_smooth_factor_left_view(wslib, gpu_ctx, oracle, smooth, levels):
