@@ -82,7 +82,6 @@ struct ws_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
     hipEvent_t ev_scratch = nullptr;      // end of the last search: the scratch planes are free again
     hipStream_t scratch_stream = nullptr; // ... the stream it ran on
-    hipEvent_t after_prepass = nullptr;   // banded host call: recorded right behind the next search's pre-pass launch
     bool scratch_busy = false;
     bool profiling = false, kernel_timed = false;
     DevBuf plane_a, plane_b, bias, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
@@ -402,10 +401,6 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         // the right view's ring runs on the packed planes after the marching kernel
         WS_HIP(ctx, launch_prepare(c, m, ia->data, ia->stride, pa, ib->data, ib->stride, pb, pbi,
                                    p->view == WS_VIEW_LEFT ? &ga : nullptr, s));
-        if (ctx->after_prepass) {
-            WS_HIP(ctx, hipEventRecord(ctx->after_prepass, s));
-            ctx->after_prepass = nullptr;
-        }
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         const int keys_pitch = (c.wa + 15) & ~15;
         if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
@@ -649,21 +644,6 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     const bool pin_o = pin_range(out, (size_t)ow * H * esz);
     rc = [&]() -> int {
     int up_to = 0; // image rows [0, up_to) are on their way up
-    // A band's map rows start down once the NEXT band's pre-pass is through, not the moment its own search is:
-    // a download in flight slows a kernel that writes as much as the pre-pass does eightfold (rocprofv3 trace:
-    // 13 -> 100-115 us beside the runtime's copy kernel and beside a copy kernel of our own on 48 workgroups
-    // alike -- the writes queue behind the ones bound for PCIe), and the next search waits for it; the search
-    // itself, which writes little, loses 5 %.
-    const void *pend_src = nullptr; // the previous band's download, not yet queued
-    int pend_y0 = 0, pend_y1 = 0, pend_k = -1;
-    auto start_pending = [&]() -> int {
-        if (pend_k < 0) return WS_OK;
-        WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[pend_k], 0));
-        WS_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(out) + (size_t)ow * pend_y0 * esz, pend_src,
-                                   (size_t)ow * (pend_y1 - pend_y0) * esz, hipMemcpyDeviceToHost, ctx->down_stream));
-        pend_k = -1;
-        return WS_OK;
-    };
     for (int k = 0; k < nb; ++k) {
         // the first band's upload and the last band's download are what nothing can hide: those two bands are
         // half as tall as the others (nb >= 3)
@@ -688,23 +668,19 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         ws_image br{dr + (size_t)a * right->stride, right->width, b - a, right->stride};
         float *bout = scratch + (size_t)ow * (a + 2 * half * k); // the band's own map: its border rows are scrap
         const void *src = bout + (size_t)ow * (y0 - a);
-        ctx->after_prepass = pend_k >= 0 ? ctx->ev_band_done[pend_k] : nullptr;
         if (out_dtype == WS_OUT_F64) { // (doubles straight from the search kernels where they only write the map)
             double *bout64 = static_cast<double *>(ctx->d_out64.p) + (size_t)ow * (a + 2 * half * k);
-            rc = run_device_f64(ctx, p, &bl, &br, bout, bout64, ow, b - a, ctx->stream);
+            if ((rc = run_device_f64(ctx, p, &bl, &br, bout, bout64, ow, b - a, ctx->stream)) != WS_OK) return rc;
             src = bout64 + (size_t)ow * (y0 - a);
-        } else {
-            rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream);
+        } else if ((rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream)) != WS_OK) {
+            return rc;
         }
-        const bool recorded = ctx->after_prepass == nullptr; // (a search without a pre-pass leaves it standing)
-        ctx->after_prepass = nullptr;
-        if (rc != WS_OK) return rc;
-        if (pend_k >= 0 && !recorded) WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[pend_k], ctx->stream));
-        if ((rc = start_pending()) != WS_OK) return rc;
-        pend_src = src; pend_y0 = y0; pend_y1 = y1; pend_k = k;
+        WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
+        WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
+        WS_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(out) + (size_t)ow * y0 * esz, src, (size_t)ow * (y1 - y0) * esz,
+                                   hipMemcpyDeviceToHost, ctx->down_stream));
     }
-    WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[pend_k], ctx->stream));
-    return start_pending();
+    return WS_OK;
     }();
     // (also after an error: nothing may still be copying when the ranges are released)
     const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream),
