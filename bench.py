@@ -245,6 +245,19 @@ def main():
                 kernel_ms[i] += ctx.last_kernel_ms() / reps
         ctx.set_profiling(False)
         info = ctx.last_launch()
+    # ... and the way the timed region runs it: with the other context's pair beside it (the last launch of
+    # every context in each of a few steps; the events sit on the launch streams and nothing waits inside a step)
+    kernel_ms_in_flight = None
+    if not dry and pairs and in_flight > 1 and len(pairs) >= in_flight:
+        for c in ctxs:
+            c.set_profiling(True)
+        samples = []
+        for _ in range(reps):
+            step()
+            samples.extend(c.last_kernel_ms() for c in ctxs)
+        for c in ctxs:
+            c.set_profiling(False)
+        kernel_ms_in_flight = sum(samples) / len(samples)
     alg_bytes = [3.0 * h * w + 3.0 * h * w + 4.0 * h * w for (w, h, _) in todo]   # both images + the f32 map
     summary = {"rank": rank, "pairs": list(mine), "kernel_ms_sum": round(sum(kernel_ms), 4),
                "alg_bytes": sum(alg_bytes), "hyps": float(sum(w * h * max_d for w, h, _ in todo))}
@@ -302,9 +315,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": info["kernel"], "kernel_ms": round(k_ms / n_launch, 4),
+                         "kernel_ms_in_flight": None if kernel_ms_in_flight is None else round(kernel_ms_in_flight, 4),
                          "launches": n_launch, "algorithmic_bytes": k_bytes / n_launch, "valu_issue": valu,
-                         "note": "stencil/reduction with D/10 hypotheses per compulsory byte: "
-                                 "VALU-issue bound, see DESIGN.md for the lane-op ceiling"},
+                         "note": "stencil/reduction with D/10 hypotheses per compulsory byte: VALU-issue bound, see "
+                                 "DESIGN.md for the lane-op ceiling; kernel_ms / achieved: the kernel alone on the "
+                                 "device, kernel_ms_in_flight: a launch of the timed region, sharing the chip with "
+                                 "the other context's pair (a rocprofv3 average of the default command mixes both)"},
         }
         if batch or world > 1:
             out["per_rank"] = [{"rank": s["rank"], "pairs": len(s["pairs"]), "kernel_ms_sum": s["kernel_ms_sum"],
