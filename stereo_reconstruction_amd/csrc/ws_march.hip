@@ -36,6 +36,10 @@
 // DESIGN.md.  Wave64 throughout; nothing here assumes 32-wide warps.
 #include "ws_device.h"
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace wsamd {
 
 // ------------------------------------------------------------------------------------------
@@ -391,24 +395,33 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 #define WS_MAXT 512
 #endif
 constexpr int kX = WS_X, kND = WS_ND, kMaxT = WS_MAXT; // build-time tuning (tools/variants.py)
+constexpr int kNDNarrow = 4;                           // the second instantiation of every window (march_nd)
 constexpr int kMaxChunks = 64; // at most 512 disparities per tile and pass (tools/time_calls.py)
 constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1536)
 
 typedef void (*MarchFn)(const MarchArgs);
 struct MarchEntry {
-    int ww, wh, ssd;
+    int ww, wh, ssd, nd;
     MarchFn fn;
     MarchFn fn_cost; // the same kernel also writing the winners' costs (right-view window sizes only)
     const char *name;
 };
-#define WS_MARCH_ENTRY(W, H)                                                                              \
-    {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H ">"}, \
-    {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H ">"}
-#define WS_MARCH_ENTRY_COST(W, H)                                                                      \
-    {W, H, 0, ws_march_kernel<kX, kND, W, H, false, kMaxT>, ws_march_kernel<kX, kND, W, H, false, kMaxT, true>, \
-     "ws_march_kernel<sad," #W "x" #H ">"},                                                            \
-    {W, H, 1, ws_march_kernel<kX, kND, W, H, true, kMaxT>, ws_march_kernel<kX, kND, W, H, true, kMaxT, true>, \
-     "ws_march_kernel<ssd," #W "x" #H ">"}
+// Every window comes with 8 and with 4 disparities per thread.  8 (64 running sums, ~180 VGPRs, two waves per
+// SIMD) is the fastest search of a config-2-like pair on an idle chip; 4 (~125 VGPRs, four waves per SIMD) reads
+// more of plane B per hypothesis but lets the workgroups of two searches -- two contexts taking a queue of
+// pairs alternately, INTEGRATION.md -- share a CU, and is level or ahead on its own for wide windows and wide
+// disparity ranges (tools/two_in_flight.py on both builds: 17x17 D=200 0.143 -> 0.134 ms alone, config 3
+// 0.96 -> 0.89 ms and config 5's search 3.20 -> 2.93 ms with two in flight; 7x7 D=256 0.176 -> 0.204 alone).
+#define WS_MARCH_ENTRY_ND(W, H, N, TAG)                                                                          \
+    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H TAG ">"}, \
+    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H TAG ">"}
+#define WS_MARCH_ENTRY_COST_ND(W, H, N, TAG)                                                                   \
+    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, ws_march_kernel<kX, N, W, H, false, kMaxT, true>, \
+     "ws_march_kernel<sad," #W "x" #H TAG ">"},                                                                \
+    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, ws_march_kernel<kX, N, W, H, true, kMaxT, true>,   \
+     "ws_march_kernel<ssd," #W "x" #H TAG ">"}
+#define WS_MARCH_ENTRY(W, H) WS_MARCH_ENTRY_ND(W, H, kND, ""), WS_MARCH_ENTRY_ND(W, H, kNDNarrow, ",nd4")
+#define WS_MARCH_ENTRY_COST(W, H) WS_MARCH_ENTRY_COST_ND(W, H, kND, ""), WS_MARCH_ENTRY_COST_ND(W, H, kNDNarrow, ",nd4")
 static const MarchEntry kMarchTable[] = {
     // left view: bs x bs
     WS_MARCH_ENTRY(3, 3), WS_MARCH_ENTRY(5, 5), WS_MARCH_ENTRY(7, 7), WS_MARCH_ENTRY(9, 9),
@@ -418,10 +431,30 @@ static const MarchEntry kMarchTable[] = {
     WS_MARCH_ENTRY_COST(10, 10), WS_MARCH_ENTRY_COST(12, 12), WS_MARCH_ENTRY_COST(14, 14), WS_MARCH_ENTRY_COST(16, 16),
 };
 
+// disparities per thread for this search: a function of the canonical problem alone, so that everything that
+// reads the marching kernel's planes afterwards (smoothFactor, sub-pixel refine) derives the same key layout
+static int march_nd(const Canon &c)
+{
+    static const int forced = [] {
+        const char *e = getenv("WS_MARCH_ND"); // development knob
+        const int v = e ? atoi(e) : 0;
+        return v == kND || v == kNDNarrow ? v : 0;
+    }();
+    if (forced) return forced;
+    if (kND == kNDNarrow) return kND;
+    // The table behind this rule: profiles/r02/nd_grid.txt (tools/two_in_flight.py --grid: windows 5..17, ranges
+    // 128 / 256 / 512, both costs at 1500 x 1000, either build alone and with two pairs in flight).
+    const int dcount = c.d_hi - c.d_lo + 1;
+    if (c.ww <= 9) return !c.ssd || dcount >= 384 ? kNDNarrow : kND; // two workgroups a CU: SAD -8..-15 % in flight
+    if (c.ww <= 14) return c.ssd ? kNDNarrow : kND;                   // SSD -7..-17 % either way, SAD +15..+27 %
+    return dcount <= 224 ? kNDNarrow : kND;                           // 15..17: -5..-8 % at 128, +6..+24 % from 256 on
+}
+
 static const MarchEntry *find_march(const Canon &c)
 {
+    const int nd = march_nd(c);
     for (const MarchEntry &e : kMarchTable)
-        if (e.ww == c.ww && e.wh == c.wh && e.ssd == c.ssd) return &e;
+        if (e.ww == c.ww && e.wh == c.wh && e.ssd == c.ssd && e.nd == nd) return &e;
     return nullptr;
 }
 
@@ -438,7 +471,7 @@ bool march_has_cost(const Canon &c)
     return e && e->fn_cost;
 }
 
-int march_centred(const Canon &c) { return c.ssd && ssd_needs_centring(c.ww, c.wh, kND); }
+int march_centred(const Canon &c) { return c.ssd && ssd_needs_centring(c.ww, c.wh, march_nd(c)); }
 
 bool march_supported(const Canon &c)
 {
@@ -448,9 +481,36 @@ bool march_supported(const Canon &c)
     if (dcount < 1) return false;
     // keys must stay inside (-2^28, 2^28)
     //   SSD: (2 * cross sum) << log2(ND)        SAD: window sum << tag bits
-    const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * (march_centred(c) ? 128 * 128 : 255 * 255) * kND
+    const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * (march_centred(c) ? 128 * 128 : 255 * 255) * march_nd(c)
                                   : ((long long)c.ww * c.wh * 3 * 255) << tag_bits_for(c);
     return worst < (long long)kValidKeyBound;
+}
+
+static int march_slots_per_cu(const Canon &c, int nd, int threads)
+{
+    static const int forced = [] {
+        const char *e = getenv("WS_PLAN_SLOTS"); // development knob
+        return e ? atoi(e) : 0;
+    }();
+    if (forced > 0) return forced;
+    const MarchEntry *e = find_march(c);
+    const int guess = nd <= kNDNarrow && threads <= 512 && c.ww <= 9 ? 2 : 1;
+    if (!e) return guess;
+    // one question per kernel and block size, asked once (LDS never is the limit at these sizes)
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const MarchEntry *, int>, int>> known;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &k : known)
+        if (k.first.first == e && k.first.second == threads) return k.second;
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void *>(e->fn), threads, 0) != hipSuccess ||
+        blocks < 1) {
+        (void)hipGetLastError();
+        return guess; // (no device: not remembered)
+    }
+    const int slots = blocks > 2 ? 2 : blocks;
+    known.push_back({{e, threads}, slots});
+    return slots;
 }
 
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
@@ -458,15 +518,16 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
 {
     if (!march_supported(c)) return false;
     MarchLaunch m{};
+    const int nd = march_nd(c);
     m.x_per_thread = kX;
-    m.nd_per_thread = kND;
+    m.nd_per_thread = nd;
     m.max_threads = kMaxT;
     const int dcount = c.d_hi - c.d_lo + 1;
     const int out_w = c.ox1 - c.ox0, out_h = c.oy1 - c.oy0;
     // d-chunks per tile.  One tile holds at most kMaxChunks chunks (wider disparity ranges would
     // leave too few columns per tile); beyond that the range is cut into equal d-group passes that
     // meet in a plane of keys.
-    const int nch_total = ceil_div(dcount, kND);
+    const int nch_total = ceil_div(dcount, nd);
     static const int max_chunks = [] {
         const char *e = getenv("WS_MAX_CHUNKS"); // development knob
         const int v = e ? atoi(e) : 0;
@@ -495,12 +556,16 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
         // R + (wh - 1) / 2 + 3 row times (the wh - 1 warm-up rows only add, the prologue is worth ~3 rows) and the
         // chip works through ceil(workgroups / CUs) rounds of them: take the strip count with the cheapest total
         // (config 3's own sweep, profiles/r01/sweep_tiles_config3.csv, has its minimum where this puts it).
+        // (With 4 disparities per thread and a window up to 9 x 9 the kernel stays within 128 VGPRs: two
+        // workgroups share a CU, four waves per SIMD, and a round is twice as many workgroups -- the runtime's
+        // occupancy figure where a device is there to ask, that rule of thumb for ws_plan without one.)
+        const int slots = march_slots_per_cu(c, nd, m.threads);
         double best_cost = 0.0;
         strips = 1;
         for (int sc = 1; sc <= out_h; ++sc) {
             const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
             if (st != sc) continue; // (the same strips as a smaller count already seen)
-            const int rounds = ceil_div(m.tiles * st, num_cus);
+            const int rounds = ceil_div(m.tiles * st, num_cus * slots);
             const double cost = rounds * (rows + 0.5 * (c.wh - 1) + 3.0);
             if (sc == 1 || cost < best_cost) { best_cost = cost; strips = sc; }
         }
@@ -508,8 +573,8 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     }
     m.strip_rows = ceil_div(out_h, strips);
     m.strips = ceil_div(out_h, m.strip_rows);
-    const int dt = m.nch * kND;
-    const int nreg = kX / 4, nregb = march_nreg_b(kX, kND);
+    const int dt = m.nch * nd;
+    const int nreg = kX / 4, nregb = march_nreg_b(kX, nd);
     const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
               b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
               bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);

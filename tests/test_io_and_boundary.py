@@ -187,15 +187,25 @@ def test_planner_choices_without_a_device(wslib):
     assert c2["strip_rows"] * c2["strips"] >= 994
     p = ws.make_params(ws.VIEW_LEFT, 9, 0, 512, 1.0, "sad")
     c3 = ws.plan(p, (1988, 2964, 3), (1988, 2964, 3))
-    rounds = -(-c3["tiles"] * c3["strips"] // 256)
-    assert c3["strip_rows"] >= 100 and rounds * 256 - c3["tiles"] * c3["strips"] < 32   # tall strips, full rounds
+    cap = 512            # 4 disparities per thread, 9 x 9: two workgroups share a CU (march_slots_per_cu)
+    rounds = -(-c3["tiles"] * c3["strips"] // cap)
+    assert c3["strip_rows"] >= 64 and rounds * cap - c3["tiles"] * c3["strips"] < 64    # tall strips, full rounds
     p = ws.make_params(ws.VIEW_LEFT, 9, 0, 1024, 1.0, "ssd")
-    assert ws.plan(p, (2160, 3840, 3), (2160, 3840, 3))["passes"] == 2                  # D = 1024: two d-group passes
+    c5 = ws.plan(p, (2160, 3840, 3), (2160, 3840, 3))                                   # D = 1024: several d-group passes
+    assert c5["passes"] >= 2 and c5["passes"] * c5["d_chunks"] * c5["d_per_thread"] >= 1024
+    # wide disparity ranges and wide windows take 4 disparities per thread (two searches can then share a CU),
+    # a config-2-like pair 8 (ws_march.hip: march_nd)
+    assert c2["d_per_thread"] == 8 and c3["d_per_thread"] == 4 and c5["d_per_thread"] == 4
+    p = ws.make_params(ws.VIEW_LEFT, 17, 0, 200, 1.0, "ssd")
+    assert ws.plan(p, (750, 900, 3), (750, 900, 3))["d_per_thread"] == 4
     for view in (ws.VIEW_LEFT, ws.VIEW_RIGHT):
         for cost in ("ssd", "sad"):
             p = ws.make_params(view, 7, 0, 3000, 1.0, cost)                              # 10 x the width
             info = ws.plan(p, (40, 300, 3), (40, 300, 3))
-            assert info["marching"] == 1 and info["passes"] == 1, (view, cost, info)
+            # the range is clamped to what the geometry allows (< 300 candidates): one pass of <= 512 of them at 8
+            # per thread, two passes of <= 256 at 4 per thread -- not the 6..12 passes 3000 candidates would take
+            assert info["marching"] == 1 and info["passes"] == (1 if info["d_per_thread"] == 8 else 2), (view, cost, info)
+            assert info["passes"] * info["d_chunks"] * info["d_per_thread"] < 2 * 300
     # what the reference rejects is rejected without a device too
     assert ws.validate(ws.make_params(ws.VIEW_LEFT, 6, 0, 16), (40, 100, 3), (40, 100, 3)) == -2
     assert ws.validate(ws.make_params(ws.VIEW_RIGHT, 7, 0, 16), (30, 100, 3), (40, 100, 3)) == -2

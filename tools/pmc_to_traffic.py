@@ -38,16 +38,25 @@ def main():
     if not march:
         raise SystemExit("no marching kernel in " + pmc_dir)
     k = max(march, key=lambda n: sum(agg[n].get("SQ_INSTS_VALU", [0])))
-    m = {c: sum(v) / len(v) for c, v in agg[k].items()}
+    # A search wider than one pass launches the kernel once per d-group pass: bench.py times the search, so the
+    # per-launch means are scaled to launches per search (counted against the pre-pass, one launch per search).
+    pre = [n for n in agg if "ws_prepare_kernel" in n]
+    per_search = 1
+    if pre and agg[pre[0]].get("SQ_INSTS_VALU") and agg[k].get("SQ_INSTS_VALU"):
+        per_search = max(1, round(len(agg[k]["SQ_INSTS_VALU"]) / len(agg[pre[0]]["SQ_INSTS_VALU"])))
+    extensive = {"FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES"}
+    m = {c: sum(v) / len(v) * (per_search if c in extensive else 1) for c, v in agg[k].items()}
     t = re.search(r"ws_march_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", k)
-    name = "ws_march_kernel<%s,%sx%s>" % ("ssd" if t.group(5) == "true" else "sad", t.group(3), t.group(4))
+    # (the name the library reports: ",nd4" marks the instantiation with 4 disparities per thread)
+    name = "ws_march_kernel<%s,%sx%s%s>" % ("ssd" if t.group(5) == "true" else "sad", t.group(3), t.group(4),
+                                            ",nd4" if t.group(2) == "4" else "")
     peak, peak_src = None, None
     if ubench and os.path.exists(ubench):
         rates = [float(x) for x in re.findall(r"march-mix \w+\s+waves/SIMD=\d+ :.*?([\d.]+) Tlane-op/s", open(ubench).read())]
         if rates:
             peak, peak_src = max(rates) * 1e12, "best sustained rate of the marching step's own instruction mix in %s" % ubench
     out = {
-        "workload": workload, "kernel": name, "kernel_symbol": k[:120],
+        "workload": workload, "kernel": name, "kernel_symbol": k[:120], "launches_per_search": per_search,
         "source": "%s (rocprofv3 --pmc, FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; tools/pmc_to_traffic.py)" % pmc_dir,
         "fetch_size_kb": m.get("FETCH_SIZE"), "write_size_kb": m.get("WRITE_SIZE"),
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads -> doubled "
@@ -57,7 +66,7 @@ def main():
         "valu_busy_per_wave": (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]) if "SQ_WAVE_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m else None,
         "wait_any_per_wave": (m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]) if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_ANY" in m else None,
         "lds_bank_conflict_frac": (m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]) if m.get("SQ_LDS_IDX_ACTIVE") else None,
-        "valu_note": "SQ_INSTS_VALU = wave instructions per launch; x64 lanes = lane-ops",
+        "valu_note": "SQ_INSTS_VALU = wave instructions per search (all its d-group passes); x64 lanes = lane-ops",
         "valu_issue_peak_lane_ops_per_s": peak, "valu_peak_source": peak_src,
     }
     with open(os.path.join(out_dir, "traffic_%s.json" % workload), "w") as f:
