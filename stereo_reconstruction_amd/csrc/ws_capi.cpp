@@ -26,6 +26,11 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct HostBuf { // pinned host memory of the library's own (hipHostMalloc)
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
+
 struct Job { // one pair in flight on the batched host path
     uint8_t *d_in = nullptr; // left image, then right image (rows with the caller's stride)
     float *d_out = nullptr;
@@ -35,6 +40,7 @@ struct Job { // one pair in flight on the batched host path
     void *user_out = nullptr;
     int w = 0, h = 0, out_stride = 0, dtype = 0;
     bool pending = false; // searched (or being searched), result not yet on its way to user_out
+    HostBuf h_left, h_right; // gathered rows of images that do not cross as one span (gather_rows)
 };
 
 thread_local std::string g_create_error; // ws_last_error(NULL): why the last ws_create on this thread failed
@@ -73,6 +79,23 @@ void unpin_range(const void *p, size_t n)
         }
 }
 
+// A caller buffer registered for the duration of a scope; released only once the stream its copies run on is idle.
+struct ScopedPin {
+    const void *p;
+    size_t n;
+    hipStream_t s;
+    bool ok;
+    ScopedPin(const void *ptr, size_t bytes, hipStream_t stream) : p(ptr), n(bytes), s(stream), ok(ptr && bytes && pin_range(ptr, bytes)) {}
+    ~ScopedPin()
+    {
+        if (!ok) return;
+        (void)hipStreamSynchronize(s);
+        unpin_range(p, n);
+    }
+    ScopedPin(const ScopedPin &) = delete;
+    ScopedPin &operator=(const ScopedPin &) = delete;
+};
+
 } // namespace
 
 struct ws_context {
@@ -92,6 +115,7 @@ struct ws_context {
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
     std::vector<std::pair<const void *, size_t>> batch_pins; // caller buffers registered by ws_enqueue_host until ws_wait
+    HostBuf h_left, h_right;              // ws_search_host: gathered rows of cut-out images (gather_rows)
     int host_bands = -1;               // ws_set_host_bands: 0 = never split, -1 = automatic
     std::string err;
     std::string last_kernel;
@@ -148,6 +172,30 @@ hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, s
 {
     if (dpitch == width_bytes && spitch == width_bytes) return hipMemcpyAsync(dst, src, width_bytes * rows, kind, s);
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
+}
+
+// A narrow cut-out of a much wider image goes through a pinned buffer of the library's own: the rows are gathered
+// on the host and cross as one dense linear copy.  (The runtime's 2-D copy from pageable memory takes a per-row
+// path, ~15 us a row; and no copy of this library reads or writes pageable memory through the runtime any more,
+// see DESIGN.md 3.5.)
+hipError_t host_ensure(HostBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return hipSuccess;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault);
+    if (e == hipSuccess) b.cap = want;
+    return e;
+}
+
+hipError_t gather_rows(HostBuf &b, const ws_image *im)
+{
+    const size_t rb = (size_t)im->width * 3;
+    hipError_t e = host_ensure(b, rb * im->height);
+    if (e != hipSuccess) return e;
+    for (int y = 0; y < im->height; ++y) memcpy(b.p + (size_t)y * rb, im->data + (size_t)y * im->stride, rb);
+    return hipSuccess;
 }
 
 // Is an image worth copying as one linear span, row padding included?  Yes unless it is a narrow
@@ -546,6 +594,8 @@ void ws_destroy(ws_context *ctx)
     for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->jobs[0].h_left, &ctx->jobs[0].h_right, &ctx->jobs[1].h_left, &ctx->jobs[1].h_right})
+        if (b->p) (void)hipHostFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.d_in) (void)hipFree(j.d_in);
         if (j.d_out) (void)hipFree(j.d_out);
@@ -745,14 +795,12 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     const bool pin_l = lin_l && pin_range(left->data, span_l), pin_r = lin_r && pin_range(right->data, span_r);
     const bool pin_o = pin_range(out, span_o);
     rc = [&]() -> int {
-        if (lin_l)
-            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, left->data, span_l, hipMemcpyHostToDevice, s));
-        else
-            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, s));
-        if (lin_r)
-            WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, right->data, span_r, hipMemcpyHostToDevice, s));
-        else
-            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_right.p, rb, right->data, right->stride, rb, right->height, hipMemcpyHostToDevice, s));
+        // (a cut-out that is not worth its whole span: gathered into pinned memory, dense rows; the call ends with
+        // a synchronisation, so the two buffers are free again when the next call gathers)
+        if (!lin_l) WS_HIP(ctx, gather_rows(ctx->h_left, left));
+        if (!lin_r) WS_HIP(ctx, gather_rows(ctx->h_right, right));
+        WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, lin_l ? left->data : ctx->h_left.p, span_l, hipMemcpyHostToDevice, s));
+        WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, lin_r ? right->data : ctx->h_right.p, span_r, hipMemcpyHostToDevice, s));
         ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
         ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
         float *dout = static_cast<float *>(ctx->d_out.p);
@@ -844,10 +892,14 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
         for (int i = 0; i < 3; ++i)
             if (ptr[i] && pin_range(ptr[i], len[i])) ctx->batch_pins.emplace_back(ptr[i], len[i]);
     }
-    if (lin_l) WS_HIP(ctx, hipMemcpyAsync(d_left, left->data, span_l, hipMemcpyHostToDevice, cs));
-    else WS_HIP(ctx, hipMemcpy2DAsync(d_left, lb, left->data, left->stride, lb, left->height, hipMemcpyHostToDevice, cs));
-    if (lin_r) WS_HIP(ctx, hipMemcpyAsync(d_right, right->data, span_r, hipMemcpyHostToDevice, cs));
-    else WS_HIP(ctx, hipMemcpy2DAsync(d_right, rb, right->data, right->stride, rb, right->height, hipMemcpyHostToDevice, cs));
+    if (!lin_l || !lin_r) {
+        // cut-outs are gathered into this job's pinned buffers: its previous upload from them must be through
+        WS_HIP(ctx, hipEventSynchronize(job.ev_h2d));
+        if (!lin_l) WS_HIP(ctx, gather_rows(job.h_left, left));
+        if (!lin_r) WS_HIP(ctx, gather_rows(job.h_right, right));
+    }
+    WS_HIP(ctx, hipMemcpyAsync(d_left, lin_l ? left->data : job.h_left.p, span_l, hipMemcpyHostToDevice, cs));
+    WS_HIP(ctx, hipMemcpyAsync(d_right, lin_r ? right->data : job.h_right.p, span_r, hipMemcpyHostToDevice, cs));
     WS_HIP(ctx, hipEventRecord(job.ev_h2d, cs));
     WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, job.ev_h2d, 0));
     ws_image dl{d_left, left->width, left->height, lin_l ? left->stride : (int)lb};
@@ -920,19 +972,23 @@ int ws_warp_nearest_host(ws_context *ctx, const double *src, int src_w, int src_
     if (!src || !dst || !m || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_stride < src_w ||
         dst_stride < dst_w)
         return fail(ctx, WS_ERR_ARG, "bad warp arguments");
-    // disparity maps are integer valued (or f32 sub-pixel): f32 on the device, CV_64F at the boundary
-    std::vector<float> hs((size_t)src_w * src_h), hd((size_t)dst_w * dst_h);
+    // disparity maps are integer valued (or f32 sub-pixel): f32 on the device, CV_64F at the boundary; the floats
+    // cross from / to pinned memory of the library's own
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ns = (size_t)src_w * src_h, nd = (size_t)dst_w * dst_h;
+    WS_HIP(ctx, host_ensure(ctx->h_left, ns * 4));
+    WS_HIP(ctx, host_ensure(ctx->h_right, nd * 4));
+    float *hs = reinterpret_cast<float *>(ctx->h_left.p), *hd = reinterpret_cast<float *>(ctx->h_right.p);
     for (int y = 0; y < src_h; ++y)
         for (int x = 0; x < src_w; ++x) hs[(size_t)y * src_w + x] = (float)src[(size_t)y * src_stride + x];
-    WS_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->d_out, hs.size() * 4)) != WS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_out64, hd.size() * 4)) != WS_OK) return rc;
-    WS_HIP(ctx, hipMemcpyAsync(ctx->d_out.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->d_out, ns * 4)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out64, nd * 4)) != WS_OK) return rc;
+    WS_HIP(ctx, hipMemcpyAsync(ctx->d_out.p, hs, ns * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = ws_warp_nearest_device(ctx, static_cast<const float *>(ctx->d_out.p), src_w, src_h, src_w, m,
                                 static_cast<float *>(ctx->d_out64.p), dst_w, dst_h, dst_w, ctx->stream);
     if (rc != WS_OK) return rc;
-    WS_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->d_out64.p, hd.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WS_HIP(ctx, hipMemcpyAsync(hd, ctx->d_out64.p, nd * 4, hipMemcpyDeviceToHost, ctx->stream));
     WS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int y = 0; y < dst_h; ++y)
         for (int x = 0; x < dst_w; ++x) dst[(size_t)y * dst_stride + x] = (double)hd[(size_t)y * dst_w + x];
@@ -954,6 +1010,7 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
     if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out64, n * 8)) != WS_OK) return rc;
     float *dmap = static_cast<float *>(ctx->d_out.p);
+    const ScopedPin pin_map(map, ((size_t)stride * (height - 1) + width) * 4, s); // (like ws_search_host: no pageable copies)
     WS_HIP(ctx, copy_rows(dmap, (size_t)width * 4, map, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
     WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
     WS_HIP(ctx, copy_rows(map, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
@@ -982,17 +1039,23 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
     float *dpos = reinterpret_cast<float *>(base);           // n * 16 bytes, 16-byte aligned
     float *ddepth = reinterpret_cast<float *>(base + n * 16); // n * 4
     uint8_t *dcol = base + n * 20;                            // n * 4
+    // the caller's buffers are registered while their copies run (like ws_search_host: no pageable copies)
+    const ScopedPin pin_in(in, ((size_t)stride * (height - 1) + width) * 4, s);
+    const ScopedPin pin_depth(depth, depth ? ((size_t)depth_stride * (height - 1) + width) * 4 : 0, s);
+    const ScopedPin pin_pos(positions, positions ? n * 16 : 0, s), pin_col(colors, positions ? n * 4 : 0, s);
+    const bool lin_bgr = positions && linear_span(bgr);
+    const ScopedPin pin_bgr(lin_bgr ? bgr->data : nullptr, lin_bgr ? (size_t)bgr->stride * (height - 1) + (size_t)width * 3 : 0, s);
     WS_HIP(ctx, copy_rows(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
     int bgr_stride = width * 3;
     if (positions) { // the colour image as one linear copy with its own row stride (see ws_search_host)
-        const bool lin = linear_span(bgr);
-        if (lin) {
+        if (lin_bgr) {
             bgr_stride = bgr->stride;
             const size_t span = (size_t)bgr->stride * (height - 1) + (size_t)width * 3;
             if ((rc = ensure(ctx, ctx->d_left, span)) != WS_OK) return rc;
             WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, bgr->data, span, hipMemcpyHostToDevice, s));
-        } else {
-            WS_HIP(ctx, hipMemcpy2DAsync(ctx->d_left.p, (size_t)width * 3, bgr->data, bgr->stride, (size_t)width * 3, height, hipMemcpyHostToDevice, s));
+        } else { // a cut-out of a much wider image: gathered rows from pinned memory of our own
+            WS_HIP(ctx, gather_rows(ctx->h_left, bgr));
+            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, ctx->h_left.p, (size_t)width * 3 * height, hipMemcpyHostToDevice, s));
         }
     }
     WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
