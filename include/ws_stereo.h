@@ -123,7 +123,10 @@ int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int
  * as called from ImageRectifier::computeDisparityMapLeft/Right (rectification.cpp:66-88)
  * and rectification_main.cpp:194-195.
  * out: h1 x w1 (LEFT) or h2 x w2 (RIGHT, LINEAR) elements of out_dtype, out_stride in
- * elements.  Copies in, runs, copies out, returns when the map is complete.
+ * elements.  Copies in, runs, copies out, returns when the map is complete.  The three buffers are
+ * registered with the HIP runtime (hipHostRegister) for the duration of the call and released before it
+ * returns -- every entry point taking host buffers does that; a buffer the caller has registered itself
+ * is used as it is.
  */
 int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left,
                    const ws_image *right, void *out, int out_stride, int out_dtype);
