@@ -445,9 +445,12 @@ static int march_nd(const Canon &c)
     // The table behind this rule: profiles/r02/nd_grid.txt (tools/two_in_flight.py --grid: windows 5..17, ranges
     // 128 / 256 / 512, both costs at 1500 x 1000, either build alone and with two pairs in flight).
     const int dcount = c.d_hi - c.d_lo + 1;
-    if (c.ww <= 9) return !c.ssd || dcount >= 384 ? kNDNarrow : kND; // two workgroups a CU: SAD -8..-15 % in flight
+    if (c.ww <= 9) return !c.ssd || dcount >= 448 ? kNDNarrow : kND; // two workgroups a CU: SAD -8..-15 % in flight;
+                                                                      // SSD -8 % from 512 on, +5 % alone at 320..384
     if (c.ww <= 14) return c.ssd ? kNDNarrow : kND;                   // SSD -7..-17 % either way, SAD +15..+27 %
-    return dcount <= 224 ? kNDNarrow : kND;                           // 15..17: -5..-8 % at 128, +6..+24 % from 256 on
+    return c.ssd && dcount <= 224 ? kNDNarrow : kND;                  // 15..17 SSD: level at 1500 x 1000, -4 % (-24 % in
+                                                                      // flight, right view) at the reference's 900 x 750,
+                                                                      // D = 200; +6..+24 % from 256 on; SAD +8 % at 192
 }
 
 static const MarchEntry *find_march(const Canon &c)
