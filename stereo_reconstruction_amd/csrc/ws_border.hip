@@ -390,7 +390,8 @@ struct RefineArgs {
     int out_pitch;
 };
 
-template <bool SSD, bool CENTRED>
+template <bool SSD, bool CENTRED, int WW = 0> // WW: the window width when it is known to the compiler (a row's loads
+                                              // are then all in flight together), 0 = g.ww
 __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs g)
 {
     const int x = g.ox0 + blockIdx.x * blockDim.x + threadIdx.x; // canonical column
@@ -410,8 +411,7 @@ __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs 
         const uint32_t *pb = g.B + (size_t)(y + g.wy0 + r) * g.pitch_b + (xb + g.wx0 + g.pad_b);
         uint32_t sm = 0, s0 = 0, sp = 0;
         uint32_t vp = pb[-1], v0 = pb[0];
-#pragma unroll 4
-        for (int i = 0; i < g.ww; ++i) {
+        auto pixel = [&](int i) {
             const uint32_t a = pa[i], vm = pb[i + 1];
             if constexpr (SSD) {
                 sm = pix_dot<CENTRED>(a, vm, sm); s0 = pix_dot<CENTRED>(a, v0, s0); sp = pix_dot<CENTRED>(a, vp, sp);
@@ -419,6 +419,13 @@ __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs 
                 sm = pix_sad(a, vm, sm); s0 = pix_sad(a, v0, s0); sp = pix_sad(a, vp, sp);
             }
             vp = v0; v0 = vm;
+        };
+        if constexpr (WW > 0) {
+#pragma unroll
+            for (int i = 0; i < WW; ++i) pixel(i);
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < g.ww; ++i) pixel(i);
         }
         if constexpr (SSD) {
             cm -= 2LL * (int32_t)sm; c0 -= 2LL * (int32_t)s0; cp -= 2LL * (int32_t)sp;
@@ -448,12 +455,17 @@ hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, P
     g.bias_shift = ilog2c(m.nd_per_thread);
     g.out = out; g.out_pitch = out_pitch;
     dim3 grid(ceil_div(c.ox1 - c.ox0, 256), c.oy1 - c.oy0);
-    if (!c.ssd)
-        hipLaunchKernelGGL((ws_refine_planes_kernel<false, false>), grid, dim3(256), 0, s, g);
-    else if (g.centred)
-        hipLaunchKernelGGL((ws_refine_planes_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((ws_refine_planes_kernel<true, false>), grid, dim3(256), 0, s, g);
+    // (the window widths of the BASELINE configs with the sub-pixel extension get the compile-time form)
+#define WS_REFINE(SSD, CEN)                                                                                       \
+    switch (c.ww) {                                                                                               \
+    case 7: hipLaunchKernelGGL((ws_refine_planes_kernel<SSD, CEN, 7>), grid, dim3(256), 0, s, g); break;          \
+    case 9: hipLaunchKernelGGL((ws_refine_planes_kernel<SSD, CEN, 9>), grid, dim3(256), 0, s, g); break;          \
+    default: hipLaunchKernelGGL((ws_refine_planes_kernel<SSD, CEN, 0>), grid, dim3(256), 0, s, g); break;         \
+    }
+    if (!c.ssd) { WS_REFINE(false, false) }
+    else if (g.centred) { WS_REFINE(true, true) }
+    else { WS_REFINE(true, false) }
+#undef WS_REFINE
     return hipGetLastError();
 }
 

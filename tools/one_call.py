@@ -7,6 +7,7 @@ ctx = ws.WindowSearch(0)
 L, R, _ = make_pair(w, h, maxd, 1)
 tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 out = torch.empty((h, w), dtype=torch.float32, device="cuda")
-p = ws.make_params({"left": 0, "right": 1, "linear": 2}[view], bs, mind, maxd, s, cost)
+sub = len(sys.argv) > 9 and sys.argv[9] == "subpixel"
+p = ws.make_params({"left": 0, "right": 1, "linear": 2}[view], bs, mind, maxd, s, cost, subpixel=sub)
 for _ in range(5): ctx.search_device(p, tl, tr, out, None)
 torch.cuda.synchronize()
