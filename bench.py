@@ -189,7 +189,7 @@ def main():
             continue
         if (w, h, sd) not in made:
             l, r, _ = make_pair(w, h, max_d, sd)
-            made[(w, h, sd)] = (l, r, torch.from_numpy(l).pin_memory().to(dev), torch.from_numpy(r).pin_memory().to(dev))
+            made[(w, h, sd)] = (l, r, torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev))
             host_pairs.append((l, r))
             tl, tr = made[(w, h, sd)][2:]
         else:

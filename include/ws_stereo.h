@@ -217,6 +217,14 @@ int ws_set_tuning(ws_context *ctx, int x_runs_per_tile, int strip_rows, int thre
  * 0 or 1 = never, 2..8 = that many.  For measurements; not part of the reference's surface.
  */
 int ws_set_host_bands(ws_context *ctx, int bands);
+/*
+ * How the bytes of the last host call's three buffers (left, right, out; for a batch: of its last pair) crossed:
+ * 0 = not a linear span (gathered rows), 1 = registered by this library for the duration of the call, 2 = memory the
+ * caller (or a framework) had pinned already, used as it is, 3 = through pinned staging memory of the library
+ * (INTEGRATION.md section 2 says when).  Stands in for nothing in the reference (cv::Mat buffers are pageable and
+ * rectification.cpp:66-88 never leaves the host); for tests and reports.
+ */
+int ws_last_host_paths(const ws_context *ctx, int how[3]);
 
 /* ---- Middlebury plumbing around the path ------------------------------------------ */
 /*

@@ -40,7 +40,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
-           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands",
+           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands", "ws_last_host_paths",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -140,6 +140,7 @@ def load_library(build_if_missing=False):
     lib.ws_last_launch_info.argtypes = [vp, ctypes.c_char_p, ci, P(ci), P(ci), P(ci)]
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_set_host_bands.argtypes = [vp, ci]
+    lib.ws_last_host_paths.argtypes = [vp, P(ci)]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
     lib.ws_pfm_write.argtypes = [ctypes.c_char_p, vp, ci, ci, ci]
     lib.ws_ppm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_uint8)), P(ci), P(ci)]
@@ -219,19 +220,25 @@ class WindowSearch:
         return out
 
     def search_many(self, params, pairs, dtype=np.float32):
-        """Batched host path (ws_enqueue_host / ws_wait) over independent pairs."""
+        """Batched host path (ws_enqueue_host / ws_wait) over independent pairs.  Whatever happens, nothing is
+        dropped before ws_wait has returned: the library copies from / into these buffers until then."""
         keep, outs = [], []
-        for left, right in pairs:
-            La, Li = _host_image(left)
-            Ra, Ri = _host_image(right)
-            shape = La.shape[:2] if params.view == VIEW_LEFT else Ra.shape[:2]
-            out = np.empty(shape, dtype=dtype)
-            code = OUT_F64 if out.dtype == np.float64 else OUT_F32
-            self._check(self._lib.ws_enqueue_host(self._h, ctypes.byref(params), ctypes.byref(Li),
-                                                  ctypes.byref(Ri), out.ctypes.data, shape[1], code))
-            keep.append((La, Ra))
-            outs.append(out)
+        try:
+            for left, right in pairs:
+                La, Li = _host_image(left)
+                Ra, Ri = _host_image(right)
+                shape = La.shape[:2] if params.view == VIEW_LEFT else Ra.shape[:2]
+                out = np.empty(shape, dtype=dtype)
+                code = OUT_F64 if out.dtype == np.float64 else OUT_F32
+                keep.append((La, Ra, Li, Ri))
+                outs.append(out)
+                self._check(self._lib.ws_enqueue_host(self._h, ctypes.byref(params), ctypes.byref(Li),
+                                                      ctypes.byref(Ri), out.ctypes.data, shape[1], code))
+        except BaseException:
+            self._lib.ws_wait(self._h)  # the pairs already enqueued still copy from / into keep and outs
+            raise
         self._check(self._lib.ws_wait(self._h))
+        del keep
         return outs
 
     # -- device buffers (torch tensors already in HBM) -------------------------------------
@@ -304,6 +311,12 @@ class WindowSearch:
         v = ctypes.c_int()
         self._check(self._lib.ws_last_max_block(self._h, block_size, ctypes.byref(v)))
         return v.value
+
+    def last_host_paths(self):
+        """How the last host call's (left, right, out) bytes crossed: 'gathered', 'registered', 'caller-pinned', 'staged'."""
+        how = (ctypes.c_int * 3)()
+        self._check(self._lib.ws_last_host_paths(self._h, how))
+        return tuple(("gathered", "registered", "caller-pinned", "staged")[v] for v in how)
 
     def set_host_bands(self, bands=-1):
         self._check(self._lib.ws_set_host_bands(self._h, bands))

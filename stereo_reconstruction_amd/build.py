@@ -31,19 +31,49 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+OBJ = os.path.join(HERE, "build")  # per-source objects (git-ignored): only what changed is compiled again
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _object_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + HEADERS if os.path.exists(d))
+
+
 def build(force=False, verbose=False):
     """Compile the shared library if it is missing or older than its sources."""
     if not force and not stale():
         return LIB
     # -ffp-contract=off: the few floating-point kernels (warp, depth, back-projection, smoothFactor)
     # must round every product like the reference's x86-64 build does; the hot kernels are integer
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    objs = []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ, name + ".o")
+        objs.append(obj)
+        if force or _object_stale(src, obj):
+            cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", src, "-o", obj + ".tmp.%d" % os.getpid()]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            jobs.append((subprocess.Popen(cmd), obj))
+    failed = False
+    for proc, obj in jobs:  # (at most len(SOURCES) = 6 compilers at once)
+        tmp_o = obj + ".tmp.%d" % os.getpid()
+        if proc.wait() == 0:
+            os.replace(tmp_o, obj)
+        else:
+            failed = True
+            if os.path.exists(tmp_o):
+                os.remove(tmp_o)
+    if failed:
+        raise RuntimeError("hipcc failed (see its messages above)")
     tmp = LIB + ".tmp.%d" % os.getpid()  # written aside and renamed: a concurrent loader never sees half a file
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     try:
-        subprocess.check_call(cmd)
+        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", tmp] + objs)
         os.replace(tmp, LIB)
     finally:
         if os.path.exists(tmp):

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <fstream>
@@ -40,61 +41,302 @@ struct Job { // one pair in flight on the batched host path
     void *user_out = nullptr;
     int w = 0, h = 0, out_stride = 0, dtype = 0;
     bool pending = false; // searched (or being searched), result not yet on its way to user_out
-    HostBuf h_left, h_right; // gathered rows of images that do not cross as one span (gather_rows)
+    HostBuf h_left, h_right; // gathered rows of images that do not cross as one span (gather_rows), or their stage
+    HostBuf h_out;           // stage of a map whose buffer cannot be registered (HostSpan)
+    int out_span = -1;       // index of this pair's output span in ws_context::batch_spans
 };
 
 thread_local std::string g_create_error; // ws_last_error(NULL): why the last ws_create on this thread failed
 
-// Caller buffers registered with the runtime for the duration of a banded boundary call: a copy from / to
-// pageable memory blocks the calling thread until it is done (measured: profiles/r02/pcie_probe.txt), so nothing
-// would overlap; registering costs microseconds on this platform.  One registry per process, reference counted
-// by (pointer, size): contexts on different threads may be handed the same images at the same time.
-struct PinnedRange { const void *p; size_t n; int refs; };
-std::mutex g_pin_mutex;
-std::vector<PinnedRange> g_pinned;
-
-bool pin_range(const void *p, size_t n)
+// rows of `width_bytes` between buffers with row pitches: one linear copy when both sides are dense
+// (the runtime's 2-D path is slow, very slow for row lengths that are not a multiple of 4 bytes)
+hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows,
+                     hipMemcpyKind kind, hipStream_t s)
 {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (PinnedRange &r : g_pinned)
-        if (r.p == p && r.n == n) { ++r.refs; return true; }
-    if (hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError(); // (registered by the caller already, overlapping another range, ...: copy unregistered)
+    if (dpitch == width_bytes && spitch == width_bytes) return hipMemcpyAsync(dst, src, width_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
+}
+
+hipError_t host_ensure(HostBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return hipSuccess;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault);
+    if (e == hipSuccess) b.cap = want;
+    return e;
+}
+
+
+// ---- caller host buffers ----------------------------------------------------------------------------------------
+// A copy from / to pageable memory blocks the calling thread for its whole duration and cannot overlap anything
+// (profiles/r02/pcie_probe.txt), so the boundary calls register the caller's buffers while their copies run.  What
+// the runtime does with registrations on this platform was measured, one scenario per process, by
+// tools/ubench/hostreg_probe.hip (profiles/r03/hostreg_probe.txt):
+//   * hipHostRegister accepts ranges that repeat, overlap or share a page with live registrations, but its map of
+//     host allocations has ONE key per base pointer: the same pointer registered under two sizes is one entry;
+//   * hipHostUnregister(p) with p inside a registered range but not itself a key of that map ENDS THE PROCESS
+//     (rocclr device.cpp:373 "Memobj map does not have ptr", abort(): one line on stderr, which a test runner that
+//     captures file descriptor 2 swallows with the process) -- e.g. the second release of a pointer registered
+//     under two sizes while a larger registration that starts below it is alive.  Round 2's registry was keyed by
+//     (pointer, size) and could issue exactly that sequence (crops of one image in a batch); with nothing around
+//     the pointer the same call merely returns hipErrorHostMemoryNotRegistered, which round 2 ignored;
+//   * a copy that starts inside a registered range and runs past its end is refused (hipErrorInvalidValue), it does
+//     not fall back to the pageable path;
+//   * a whole hipHostMalloc'd block cannot be registered again (hipErrorInvalidValue), a part of one can;
+//   * hipHostUnregister waits for copies in flight; the first registration of a range costs 0.1-1 ms (page
+//     faults included), the same range again about 1 us.
+// Rules that follow, enforced by HostRanges below:
+//   1. this library registers page-aligned ranges that are pairwise DISJOINT; a request inside a live range of its
+//      own shares it (reference count), buffers of one call whose pages overlap are registered as one hull;
+//   2. it only ever unregisters base pointers it registered itself, once, and reports a failing status;
+//   3. memory the runtime already knows (the caller's own hipHostMalloc / hipHostRegister, a framework's pinned
+//      allocator) is never registered or released here: copies use it as it is;
+//   4. whatever cannot be registered under 1-3 (partial overlap with a live range, a range the runtime knows in
+//      part, a refused registration or a refused direct copy) crosses through pinned staging memory of the
+//      library's own -- never through the runtime's pageable copy path.
+struct OwnRange { uintptr_t lo, hi; int refs; };
+std::mutex g_host_mutex;
+std::vector<OwnRange> g_own; // disjoint; each one is exactly one hipHostRegister(lo, hi - lo) made here
+
+uintptr_t host_page()
+{
+    static const uintptr_t ps = [] { const long v = sysconf(_SC_PAGESIZE); return v > 0 ? (uintptr_t)v : (uintptr_t)4096; }();
+    return ps;
+}
+
+bool runtime_knows(uintptr_t q)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, reinterpret_cast<const void *>(q)) != hipSuccess) {
+        (void)hipGetLastError();
         return false;
     }
-    g_pinned.push_back({p, n, 1});
-    return true;
+    return a.type != hipMemoryTypeUnregistered;
 }
 
-void unpin_range(const void *p, size_t n)
-{
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (size_t i = 0; i < g_pinned.size(); ++i)
-        if (g_pinned[i].p == p && g_pinned[i].n == n) {
-            if (--g_pinned[i].refs == 0) {
-                (void)hipHostUnregister(const_cast<void *>(p));
-                g_pinned.erase(g_pinned.begin() + (long)i);
-            }
-            return;
-        }
-}
-
-// A caller buffer registered for the duration of a scope; released only once the stream its copies run on is idle.
-struct ScopedPin {
-    const void *p;
-    size_t n;
-    hipStream_t s;
-    bool ok;
-    ScopedPin(const void *ptr, size_t bytes, hipStream_t stream) : p(ptr), n(bytes), s(stream), ok(ptr && bytes && pin_range(ptr, bytes)) {}
-    ~ScopedPin()
-    {
-        if (!ok) return;
-        (void)hipStreamSynchronize(s);
-        unpin_range(p, n);
-    }
-    ScopedPin(const ScopedPin &) = delete;
-    ScopedPin &operator=(const ScopedPin &) = delete;
+// One caller buffer for the duration of a call (or of a batch): how its bytes cross.
+struct HostSpan {
+    enum How { kUnused, kOurs, kCallerPinned, kStaged };
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    How how = kUnused;
+    uintptr_t own_lo = 0;     // kOurs: the registration it shares
+    HostBuf *stage = nullptr; // where its bytes cross if they cannot cross directly (set by the call site, always)
+    bool loaded = false;      // uploads: the stage holds the caller's bytes
+    struct Seg { size_t stage_off, host_off, row_bytes, rows, host_pitch; };
+    std::vector<Seg> down;    // downloads that went to the stage: handed to the caller by spans_finish
+    const char *why = "";     // kStaged: the reason (tests, ws_host_path_info)
 };
+
+// Classify and register the buffers of one call.  Spans with p == nullptr or n == 0 stay kUnused.
+void spans_attach(HostSpan *sp, int count, std::string *note)
+{
+    const uintptr_t ps = host_page();
+    struct Hull { uintptr_t lo, hi; };
+    std::vector<Hull> hulls;
+    std::vector<int> hull_of((size_t)count, -1);
+    // buffers of this call whose page ranges overlap (left / right views of one array, small buffers on one page)
+    // become one hull, registered once
+    for (int i = 0; i < count; ++i) {
+        if (!sp[i].p || !sp[i].n) continue;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(sp[i].p);
+        Hull h{a & ~(ps - 1), (a + sp[i].n + ps - 1) & ~(ps - 1)};
+        int into = -1;
+        for (size_t k = 0; k < hulls.size(); ++k) {
+            if (h.lo < hulls[k].hi && hulls[k].lo < h.hi) {
+                if (into < 0) {
+                    hulls[k].lo = std::min(hulls[k].lo, h.lo);
+                    hulls[k].hi = std::max(hulls[k].hi, h.hi);
+                    into = (int)k;
+                    h = hulls[k];
+                } else { // h (now part of hull `into`) also reaches hull k: fold k into it
+                    hulls[(size_t)into].lo = std::min(hulls[(size_t)into].lo, hulls[k].lo);
+                    hulls[(size_t)into].hi = std::max(hulls[(size_t)into].hi, hulls[k].hi);
+                    for (int j = 0; j < i; ++j) if (hull_of[(size_t)j] == (int)k) hull_of[(size_t)j] = into;
+                    hulls[k].lo = hulls[k].hi = 0; // (emptied, keeps the indices stable)
+                    h = hulls[(size_t)into];
+                }
+            }
+        }
+        if (into < 0) { hulls.push_back(h); into = (int)hulls.size() - 1; }
+        hull_of[(size_t)i] = into;
+    }
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    for (size_t k = 0; k < hulls.size(); ++k) {
+        const Hull h = hulls[k];
+        if (h.lo == h.hi) continue;
+        HostSpan::How how = HostSpan::kStaged;
+        const char *why = "";
+        uintptr_t own = 0;
+        bool done = false;
+        for (OwnRange &r : g_own) // inside a live range of ours: shared
+            if (r.lo <= h.lo && h.hi <= r.hi) { ++r.refs; how = HostSpan::kOurs; own = r.lo; done = true; break; }
+        if (!done)
+            for (const OwnRange &r : g_own)
+                if (h.lo < r.hi && r.lo < h.hi) { why = "overlaps a live registration of this library in part"; done = true; break; }
+        if (!done) {
+            // what the runtime knows already is the caller's (or a framework's): never registered or released here
+            bool first = true, all = true, any = false;
+            for (int i = 0; i < count; ++i) {
+                if (hull_of[(size_t)i] != (int)k) continue;
+                const uintptr_t a = reinterpret_cast<uintptr_t>(sp[i].p);
+                const bool k0 = runtime_knows(a), k1 = runtime_knows(a + sp[i].n - 1);
+                all = all && k0 && k1;
+                any = any || k0 || k1;
+                first = false;
+            }
+            any = any || runtime_knows(h.lo) || runtime_knows(h.hi - 1);
+            if (!first && all) {
+                how = HostSpan::kCallerPinned;
+            } else if (any) {
+                why = "the runtime knows a part of the range (registered or allocated by the caller)";
+            } else {
+                const hipError_t e = hipHostRegister(reinterpret_cast<void *>(h.lo), h.hi - h.lo, hipHostRegisterDefault);
+                if (e == hipSuccess) {
+                    // The runtime resolves an address to the registration with the nearest base below it and looks no
+                    // further: a registration of the caller's INSIDE this range (neither end of it, so not seen above)
+                    // would shadow ours for every byte behind its base -- copies there would be refused or take the
+                    // pageable path.  Ours is clean iff its last byte resolves to an object of exactly its size.
+                    hipDeviceptr_t base = nullptr;
+                    size_t size = 0;
+                    if (hipMemGetAddressRange(&base, &size, reinterpret_cast<hipDeviceptr_t>(h.hi - 1)) == hipSuccess && size == h.hi - h.lo) {
+                        g_own.push_back({h.lo, h.hi, 1});
+                        how = HostSpan::kOurs;
+                        own = h.lo;
+                    } else {
+                        (void)hipGetLastError();
+                        const hipError_t eu = hipHostUnregister(reinterpret_cast<void *>(h.lo)); // (h.lo is a key: just made, and nobody's before)
+                        if (eu != hipSuccess) {
+                            (void)hipGetLastError();
+                            if (note) *note = std::string("hipHostUnregister: ") + hipGetErrorName(eu);
+                        }
+                        why = "a registration of the caller's lies inside the range";
+                    }
+                } else {
+                    (void)hipGetLastError();
+                    why = "hipHostRegister refused the range";
+                    if (note) *note = std::string("hipHostRegister: ") + hipGetErrorName(e);
+                }
+            }
+        }
+        bool first_of_hull = true;
+        for (int i = 0; i < count; ++i) {
+            if (hull_of[(size_t)i] != (int)k) continue;
+            sp[i].how = how;
+            sp[i].own_lo = own;
+            sp[i].why = why;
+            if (how == HostSpan::kOurs && !first_of_hull) // one reference per span, so that every span releases its own
+                for (OwnRange &r : g_own) if (r.lo == own) { ++r.refs; break; }
+            first_of_hull = false;
+        }
+    }
+}
+
+hipError_t stage_for(HostSpan &sp)
+{
+    if (!sp.stage) return hipErrorInvalidValue;
+    return host_ensure(*sp.stage, sp.n);
+}
+
+// bytes [off, off + bytes) of the caller's buffer -> device
+hipError_t span_upload(HostSpan &sp, size_t off, void *dev, size_t bytes, hipStream_t s)
+{
+    if (off + bytes > sp.n) return hipErrorInvalidValue;
+    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
+        const hipError_t e = hipMemcpyAsync(dev, sp.p + off, bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+        (void)hipGetLastError(); // caller-pinned memory the runtime will not copy from as one range: through the stage
+        sp.how = HostSpan::kStaged;
+        sp.why = "the runtime refused a direct copy from caller-pinned memory";
+    }
+    if (sp.how != HostSpan::kStaged) return hipErrorInvalidValue;
+    if (!sp.loaded) {
+        const hipError_t e = stage_for(sp);
+        if (e != hipSuccess) return e;
+        memcpy(sp.stage->p, sp.p, sp.n);
+        sp.loaded = true;
+    }
+    return hipMemcpyAsync(dev, sp.stage->p + off, bytes, hipMemcpyHostToDevice, s);
+}
+
+// rows of `row_bytes`, `pitch` bytes apart in the caller's buffer from byte `off` on -> dense rows on the device
+hipError_t span_upload_rows(HostSpan &sp, size_t off, size_t pitch, void *dev, size_t row_bytes, size_t rows, hipStream_t s)
+{
+    if (!rows || !row_bytes) return hipSuccess;
+    if (off + pitch * (rows - 1) + row_bytes > sp.n) return hipErrorInvalidValue;
+    if (pitch == row_bytes) return span_upload(sp, off, dev, row_bytes * rows, s);
+    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
+        const hipError_t e = hipMemcpy2DAsync(dev, row_bytes, sp.p + off, pitch, row_bytes, rows, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+        (void)hipGetLastError();
+        sp.how = HostSpan::kStaged;
+        sp.why = "the runtime refused a direct copy from caller-pinned memory";
+    }
+    if (sp.how != HostSpan::kStaged) return hipErrorInvalidValue;
+    const hipError_t e = stage_for(sp);
+    if (e != hipSuccess) return e;
+    for (size_t r = 0; r < rows; ++r) memcpy(sp.stage->p + r * row_bytes, sp.p + off + r * pitch, row_bytes); // dense in the stage
+    return hipMemcpyAsync(dev, sp.stage->p, row_bytes * rows, hipMemcpyHostToDevice, s);
+}
+
+// `rows` dense rows of `row_bytes` on the device -> the caller's buffer from byte `off` on, rows `pitch` bytes apart
+hipError_t span_download(HostSpan &sp, size_t off, size_t pitch, const void *dev, size_t row_bytes, size_t rows, hipStream_t s)
+{
+    if (!rows || !row_bytes) return hipSuccess;
+    if (off + pitch * (rows - 1) + row_bytes > sp.n) return hipErrorInvalidValue;
+    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
+        const hipError_t e = copy_rows(sp.p + off, pitch, dev, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+        (void)hipGetLastError();
+        sp.how = HostSpan::kStaged;
+        sp.why = "the runtime refused a direct copy to caller-pinned memory";
+    }
+    if (sp.how != HostSpan::kStaged) return hipErrorInvalidValue;
+    const hipError_t e = stage_for(sp);
+    if (e != hipSuccess) return e;
+    // dense in the stage, at the offset of its first byte in the caller's buffer (the stage is as long as the buffer)
+    sp.down.push_back({off, off, row_bytes, rows, pitch});
+    return hipMemcpyAsync(sp.stage->p + off, dev, row_bytes * rows, hipMemcpyDeviceToHost, s);
+}
+
+// Hand staged downloads to the caller and release the registrations.  ONLY after every stream that carried a copy of
+// these spans is idle.  Returns false (and a note) if the runtime refused a release: a bug to be reported, not ignored.
+void span_scatter(HostSpan &sp) // (the copies into the stage are through: the caller of this has synchronised)
+{
+    for (const HostSpan::Seg &g : sp.down)
+        for (size_t r = 0; r < g.rows; ++r)
+            memcpy(sp.p + g.host_off + r * g.host_pitch, sp.stage->p + g.stage_off + r * g.row_bytes, g.row_bytes);
+    sp.down.clear();
+}
+
+bool spans_finish(HostSpan *sp, int count, std::string *note)
+{
+    bool ok = true;
+    for (int i = 0; i < count; ++i) span_scatter(sp[i]);
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    for (int i = 0; i < count; ++i) {
+        if (sp[i].how == HostSpan::kOurs) {
+            for (size_t k = 0; k < g_own.size(); ++k) {
+                if (g_own[k].lo != sp[i].own_lo) continue;
+                if (--g_own[k].refs == 0) {
+                    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(g_own[k].lo));
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        ok = false;
+                        if (note) *note = std::string("hipHostUnregister: ") + hipGetErrorName(e);
+                    }
+                    g_own.erase(g_own.begin() + (long)k);
+                }
+                break;
+            }
+        }
+        sp[i].how = HostSpan::kUnused;
+    }
+    return ok;
+}
 
 } // namespace
 
@@ -114,8 +356,10 @@ struct ws_context {
     hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
-    std::vector<std::pair<const void *, size_t>> batch_pins; // caller buffers registered by ws_enqueue_host until ws_wait
-    HostBuf h_left, h_right;              // ws_search_host: gathered rows of cut-out images (gather_rows)
+    int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
+    std::vector<HostSpan> batch_spans; // caller buffers of the pairs enqueued since the last ws_wait (released there)
+    HostBuf h_left, h_right, h_out;    // ws_search_host: gathered rows of cut-out images (gather_rows), stages (HostSpan)
+    HostBuf h_aux[2];                  // stages of the consumers' further buffers
     int host_bands = -1;               // ws_set_host_bands: 0 = never split, -1 = automatic
     std::string err;
     std::string last_kernel;
@@ -165,30 +409,10 @@ int ensure(ws_context *ctx, DevBuf &b, size_t bytes)
     return WS_OK;
 }
 
-// rows of `width_bytes` between buffers with row pitches: one linear copy when both sides are dense
-// (the runtime's 2-D path is slow, very slow for row lengths that are not a multiple of 4 bytes)
-hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows,
-                     hipMemcpyKind kind, hipStream_t s)
-{
-    if (dpitch == width_bytes && spitch == width_bytes) return hipMemcpyAsync(dst, src, width_bytes * rows, kind, s);
-    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
-}
-
 // A narrow cut-out of a much wider image goes through a pinned buffer of the library's own: the rows are gathered
 // on the host and cross as one dense linear copy.  (The runtime's 2-D copy from pageable memory takes a per-row
 // path, ~15 us a row; and no copy of this library reads or writes pageable memory through the runtime any more,
 // see DESIGN.md 3.5.)
-hipError_t host_ensure(HostBuf &b, size_t bytes)
-{
-    if (bytes <= b.cap) return hipSuccess;
-    if (b.p) (void)hipHostFree(b.p);
-    b.p = nullptr; b.cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault);
-    if (e == hipSuccess) b.cap = want;
-    return e;
-}
-
 hipError_t gather_rows(HostBuf &b, const ws_image *im)
 {
     const size_t rb = (size_t)im->width * 3;
@@ -589,12 +813,15 @@ void ws_destroy(ws_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-    for (const auto &r : ctx->batch_pins) unpin_range(r.first, r.second);
-    ctx->batch_pins.clear();
+    if (!ctx->batch_spans.empty()) { // a batch that was never waited for: its copies are through (synchronised above)
+        (void)spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), nullptr);
+        ctx->batch_spans.clear();
+    }
     for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-    for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->jobs[0].h_left, &ctx->jobs[0].h_right, &ctx->jobs[1].h_left, &ctx->jobs[1].h_right})
+    for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->h_out, &ctx->h_aux[0], &ctx->h_aux[1], &ctx->jobs[0].h_left, &ctx->jobs[0].h_right,
+                       &ctx->jobs[0].h_out, &ctx->jobs[1].h_left, &ctx->jobs[1].h_right, &ctx->jobs[1].h_out})
         if (b->p) (void)hipHostFree(b->p);
     for (Job &j : ctx->jobs) {
         if (j.d_in) (void)hipFree(j.d_in);
@@ -690,8 +917,13 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     uint8_t *dl = static_cast<uint8_t *>(ctx->d_left.p), *dr = static_cast<uint8_t *>(ctx->d_right.p);
     float *scratch = static_cast<float *>(ctx->d_out.p);
-    const bool pin_l = pin_range(left->data, span_l), pin_r = pin_range(right->data, span_r);
-    const bool pin_o = pin_range(out, (size_t)ow * H * esz);
+    // the caller's three buffers for the duration of the call (HostSpan: registered, caller-pinned or staged)
+    HostSpan sp[3];
+    sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left;
+    sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right;
+    sp[2].p = static_cast<uint8_t *>(out); sp[2].n = (size_t)ow * H * esz; sp[2].stage = &ctx->h_out;
+    std::string note;
+    spans_attach(sp, 3, &note);
     rc = [&]() -> int {
     int up_to = 0; // image rows [0, up_to) are on their way up
     for (int k = 0; k < nb; ++k) {
@@ -708,8 +940,8 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         if (b > up_to) { // the rows this band adds: one linear copy per image, row padding included
             const size_t ol = (size_t)up_to * left->stride, orr = (size_t)up_to * right->stride;
             const size_t nl = (size_t)(b - 1 - up_to) * left->stride + lb, nr = (size_t)(b - 1 - up_to) * right->stride + rb;
-            WS_HIP(ctx, hipMemcpyAsync(dl + ol, left->data + ol, nl, hipMemcpyHostToDevice, ctx->copy_stream));
-            WS_HIP(ctx, hipMemcpyAsync(dr + orr, right->data + orr, nr, hipMemcpyHostToDevice, ctx->copy_stream));
+            WS_HIP(ctx, span_upload(sp[0], ol, dl + ol, nl, ctx->copy_stream));
+            WS_HIP(ctx, span_upload(sp[1], orr, dr + orr, nr, ctx->copy_stream));
             up_to = b;
         }
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_up[k], ctx->copy_stream));
@@ -727,20 +959,26 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         }
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
         WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
-        WS_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(out) + (size_t)ow * y0 * esz, src, (size_t)ow * (y1 - y0) * esz,
-                                   hipMemcpyDeviceToHost, ctx->down_stream));
+        WS_HIP(ctx, span_download(sp[2], (size_t)ow * y0 * esz, (size_t)ow * esz, src, (size_t)ow * esz, (size_t)(y1 - y0), ctx->down_stream));
     }
     return WS_OK;
     }();
     // (also after an error: nothing may still be copying when the ranges are released)
     const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream),
                      e3 = hipStreamSynchronize(ctx->down_stream);
-    if (pin_l) unpin_range(left->data, span_l);
-    if (pin_r) unpin_range(right->data, span_r);
-    if (pin_o) unpin_range(out, (size_t)ow * H * esz);
+    for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)sp[i].how;
+    const bool released = spans_finish(sp, 3, &note);
     if (rc == WS_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
         return fail(ctx, WS_ERR_HIP, "banded host call: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
+    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "banded host call: %s", note.c_str());
     return rc;
+}
+
+int ws_last_host_paths(const ws_context *ctx, int how[3])
+{
+    if (!ctx || !how) return WS_ERR_ARG;
+    for (int i = 0; i < 3; ++i) how[i] = ctx->last_how[i];
+    return WS_OK;
 }
 
 int ws_set_host_bands(ws_context *ctx, int bands)
@@ -787,20 +1025,25 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * oh * 4)) != WS_OK) return rc;
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
-    // The caller's buffers are registered for the call here too, like in the banded and the batched path: every
-    // host copy of this library then goes the same way, whatever the band setting of the moment, instead of a
-    // buffer being pinned by the runtime behind the scenes in one call (its path for pageable copies of a
-    // megabyte and more) and registered by us in the next.
+    // The caller's buffers for the duration of the call (HostSpan): registered, caller-pinned or staged -- every
+    // host copy of this library goes the same way, whatever the band setting of the moment, and none through the
+    // runtime's pageable path.
     const size_t span_o = ((size_t)out_stride * (oh - 1) + ow) * esz;
-    const bool pin_l = lin_l && pin_range(left->data, span_l), pin_r = lin_r && pin_range(right->data, span_r);
-    const bool pin_o = pin_range(out, span_o);
+    HostSpan sp[3];
+    if (lin_l) { sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left; }
+    if (lin_r) { sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right; }
+    sp[2].p = static_cast<uint8_t *>(out); sp[2].n = span_o; sp[2].stage = &ctx->h_out;
+    std::string note;
+    spans_attach(sp, 3, &note);
     rc = [&]() -> int {
         // (a cut-out that is not worth its whole span: gathered into pinned memory, dense rows; the call ends with
         // a synchronisation, so the two buffers are free again when the next call gathers)
         if (!lin_l) WS_HIP(ctx, gather_rows(ctx->h_left, left));
         if (!lin_r) WS_HIP(ctx, gather_rows(ctx->h_right, right));
-        WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, lin_l ? left->data : ctx->h_left.p, span_l, hipMemcpyHostToDevice, s));
-        WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, lin_r ? right->data : ctx->h_right.p, span_r, hipMemcpyHostToDevice, s));
+        if (lin_l) WS_HIP(ctx, span_upload(sp[0], 0, ctx->d_left.p, span_l, s));
+        else WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, ctx->h_left.p, span_l, hipMemcpyHostToDevice, s));
+        if (lin_r) WS_HIP(ctx, span_upload(sp[1], 0, ctx->d_right.p, span_r, s));
+        else WS_HIP(ctx, hipMemcpyAsync(ctx->d_right.p, ctx->h_right.p, span_r, hipMemcpyHostToDevice, s));
         ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
         ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
         float *dout = static_cast<float *>(ctx->d_out.p);
@@ -812,18 +1055,15 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
         } else if ((rc2 = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) {
             return rc2;
         }
-        if (out_stride == ow)
-            WS_HIP(ctx, hipMemcpyAsync(out, src, (size_t)ow * oh * esz, hipMemcpyDeviceToHost, s));
-        else
-            WS_HIP(ctx, hipMemcpy2DAsync(out, (size_t)out_stride * esz, src, (size_t)ow * esz, (size_t)ow * esz, oh, hipMemcpyDeviceToHost, s));
+        WS_HIP(ctx, span_download(sp[2], 0, (size_t)out_stride * esz, src, (size_t)ow * esz, (size_t)oh, s));
         return WS_OK;
     }();
     // (also after an error: nothing may still be copying when the ranges are released)
     const hipError_t es = hipStreamSynchronize(s);
-    if (pin_l) unpin_range(left->data, span_l);
-    if (pin_r) unpin_range(right->data, span_r);
-    if (pin_o) unpin_range(out, span_o);
+    for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)sp[i].how;
+    const bool released = spans_finish(sp, 3, &note);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "host call: %s", hipGetErrorString(es));
+    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "host call: %s", note.c_str());
     return rc;
 }
 
@@ -837,11 +1077,8 @@ static int flush_job(ws_context *ctx, Job &j)
     WS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, j.ev_done, 0));
     const size_t esz = j.dtype == WS_OUT_F32 ? 4 : 8;
     const void *src = j.dtype == WS_OUT_F32 ? static_cast<const void *>(j.d_out) : static_cast<const void *>(j.d_out64);
-    if (j.out_stride == j.w)
-        WS_HIP(ctx, hipMemcpyAsync(j.user_out, src, (size_t)j.w * j.h * esz, hipMemcpyDeviceToHost, ctx->copy_stream));
-    else
-        WS_HIP(ctx, hipMemcpy2DAsync(j.user_out, (size_t)j.out_stride * esz, src, (size_t)j.w * esz, (size_t)j.w * esz, j.h,
-                                     hipMemcpyDeviceToHost, ctx->copy_stream));
+    WS_HIP(ctx, span_download(ctx->batch_spans[(size_t)j.out_span], 0, (size_t)j.out_stride * esz, src, (size_t)j.w * esz, (size_t)j.h,
+                              ctx->copy_stream));
     return WS_OK;
 }
 
@@ -859,6 +1096,13 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     Job &job = ctx->jobs[ctx->job_next];
     Job &prev = ctx->jobs[ctx->job_next ^ 1];
     if ((rc = flush_job(ctx, job)) != WS_OK) return rc; // (only after an error left it pending)
+    // this slot's previous pair: a map that came down through the slot's stage goes to its caller now, before the
+    // stage is used again
+    if (job.out_span >= 0 && !ctx->batch_spans[(size_t)job.out_span].down.empty()) {
+        WS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        span_scatter(ctx->batch_spans[(size_t)job.out_span]);
+    }
+    job.out_span = -1;
     const size_t lb = (size_t)left->width * 3, rb = (size_t)right->width * 3;
     const bool lin_l = linear_span(left), lin_r = linear_span(right);
     const size_t span_l = lin_l ? (size_t)left->stride * (left->height - 1) + lb : lb * left->height;
@@ -883,23 +1127,32 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     }
     uint8_t *d_left = job.d_in, *d_right = job.d_in + off_r;
     hipStream_t cs = ctx->copy_stream;
-    // registered for the life of the batch (ws_wait releases them): copies from / to pageable memory would block
-    // this thread until they are done, and the next pair's upload could not run beside this pair's search
-    {
-        const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
-        const void *ptr[3] = {lin_l ? left->data : nullptr, lin_r ? right->data : nullptr, out};
-        const size_t len[3] = {span_l, span_r, ((size_t)out_stride * (oh - 1) + ow) * esz};
-        for (int i = 0; i < 3; ++i)
-            if (ptr[i] && pin_range(ptr[i], len[i])) ctx->batch_pins.emplace_back(ptr[i], len[i]);
-    }
-    if (!lin_l || !lin_r) {
-        // cut-outs are gathered into this job's pinned buffers: its previous upload from them must be through
+    // The caller's buffers for the life of the batch (HostSpan; ws_wait releases them): copies from / to pageable
+    // memory would block this thread until they are done, and the next pair's upload could not run beside this
+    // pair's search.
+    const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+    HostSpan sp[3];
+    if (lin_l) { sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &job.h_left; }
+    if (lin_r) { sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &job.h_right; }
+    sp[2].p = static_cast<uint8_t *>(out); sp[2].n = ((size_t)out_stride * (oh - 1) + ow) * esz; sp[2].stage = &job.h_out;
+    std::string note;
+    spans_attach(sp, 3, &note);
+    const size_t first = ctx->batch_spans.size();
+    for (int i = 0; i < 3; ++i) ctx->batch_spans.push_back(sp[i]);
+    HostSpan *bs = ctx->batch_spans.data() + first; // (valid until the next push_back: only used inside this call)
+    job.out_span = (int)first + 2;
+    const bool direct = (!lin_l || bs[0].how == HostSpan::kOurs) && (!lin_r || bs[1].how == HostSpan::kOurs);
+    if (!lin_l || !lin_r || !direct) {
+        // bytes that cross through this slot's pinned buffers (gathered cut-outs, stages): the slot's previous upload
+        // from them must be through
         WS_HIP(ctx, hipEventSynchronize(job.ev_h2d));
         if (!lin_l) WS_HIP(ctx, gather_rows(job.h_left, left));
         if (!lin_r) WS_HIP(ctx, gather_rows(job.h_right, right));
     }
-    WS_HIP(ctx, hipMemcpyAsync(d_left, lin_l ? left->data : job.h_left.p, span_l, hipMemcpyHostToDevice, cs));
-    WS_HIP(ctx, hipMemcpyAsync(d_right, lin_r ? right->data : job.h_right.p, span_r, hipMemcpyHostToDevice, cs));
+    if (lin_l) WS_HIP(ctx, span_upload(bs[0], 0, d_left, span_l, cs));
+    else WS_HIP(ctx, hipMemcpyAsync(d_left, job.h_left.p, span_l, hipMemcpyHostToDevice, cs));
+    if (lin_r) WS_HIP(ctx, span_upload(bs[1], 0, d_right, span_r, cs));
+    else WS_HIP(ctx, hipMemcpyAsync(d_right, job.h_right.p, span_r, hipMemcpyHostToDevice, cs));
     WS_HIP(ctx, hipEventRecord(job.ev_h2d, cs));
     WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, job.ev_h2d, 0));
     ws_image dl{d_left, left->width, left->height, lin_l ? left->stride : (int)lb};
@@ -923,11 +1176,17 @@ int ws_wait(ws_context *ctx)
     WS_HIP(ctx, hipSetDevice(ctx->device));
     int rc = flush_job(ctx, ctx->jobs[ctx->job_next]); // the older one first
     if (rc == WS_OK) rc = flush_job(ctx, ctx->jobs[ctx->job_next ^ 1]);
+    for (Job &j : ctx->jobs) j.pending = false; // (after an error nothing stays queued for a later batch)
     const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
-    for (const auto &r : ctx->batch_pins) unpin_range(r.first, r.second);
-    ctx->batch_pins.clear();
+    std::string note;
+    if (ctx->batch_spans.size() >= 3)
+        for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)ctx->batch_spans[ctx->batch_spans.size() - 3 + (size_t)i].how;
+    const bool released = spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), &note);
+    ctx->batch_spans.clear();
+    ctx->jobs[0].out_span = ctx->jobs[1].out_span = -1;
     if (e1 != hipSuccess || e2 != hipSuccess)
         return fail(ctx, WS_ERR_HIP, "ws_wait: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "ws_wait: %s", note.c_str());
     return rc;
 }
 
@@ -1010,12 +1269,22 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
     if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out64, n * 8)) != WS_OK) return rc;
     float *dmap = static_cast<float *>(ctx->d_out.p);
-    const ScopedPin pin_map(map, ((size_t)stride * (height - 1) + width) * 4, s); // (like ws_search_host: no pageable copies)
-    WS_HIP(ctx, copy_rows(dmap, (size_t)width * 4, map, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
-    WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
-    WS_HIP(ctx, copy_rows(map, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
-    WS_HIP(ctx, hipStreamSynchronize(s));
-    return WS_OK;
+    // the caller's map for the duration of the call (HostSpan, like ws_search_host: no pageable copies)
+    HostSpan sp[1];
+    sp[0].p = reinterpret_cast<uint8_t *>(map); sp[0].n = ((size_t)stride * (height - 1) + width) * 4; sp[0].stage = &ctx->h_out;
+    std::string note;
+    spans_attach(sp, 1, &note);
+    rc = [&]() -> int {
+        WS_HIP(ctx, span_upload_rows(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
+        WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
+        WS_HIP(ctx, span_download(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
+        return WS_OK;
+    }();
+    const hipError_t es = hipStreamSynchronize(s);
+    const bool released = spans_finish(sp, 1, &note);
+    if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", hipGetErrorString(es));
+    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", note.c_str());
+    return rc;
 }
 
 static int depth_vertices_host(ws_context *ctx, const float *in, int width, int height, int stride, int input_is_depth,
@@ -1039,36 +1308,47 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
     float *dpos = reinterpret_cast<float *>(base);           // n * 16 bytes, 16-byte aligned
     float *ddepth = reinterpret_cast<float *>(base + n * 16); // n * 4
     uint8_t *dcol = base + n * 20;                            // n * 4
-    // the caller's buffers are registered while their copies run (like ws_search_host: no pageable copies)
-    const ScopedPin pin_in(in, ((size_t)stride * (height - 1) + width) * 4, s);
-    const ScopedPin pin_depth(depth, depth ? ((size_t)depth_stride * (height - 1) + width) * 4 : 0, s);
-    const ScopedPin pin_pos(positions, positions ? n * 16 : 0, s), pin_col(colors, positions ? n * 4 : 0, s);
+    // the caller's buffers for the duration of the call (HostSpan, like ws_search_host: no pageable copies)
     const bool lin_bgr = positions && linear_span(bgr);
-    const ScopedPin pin_bgr(lin_bgr ? bgr->data : nullptr, lin_bgr ? (size_t)bgr->stride * (height - 1) + (size_t)width * 3 : 0, s);
-    WS_HIP(ctx, copy_rows(din, (size_t)width * 4, in, (size_t)stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, s));
-    int bgr_stride = width * 3;
-    if (positions) { // the colour image as one linear copy with its own row stride (see ws_search_host)
-        if (lin_bgr) {
-            bgr_stride = bgr->stride;
-            const size_t span = (size_t)bgr->stride * (height - 1) + (size_t)width * 3;
-            if ((rc = ensure(ctx, ctx->d_left, span)) != WS_OK) return rc;
-            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, bgr->data, span, hipMemcpyHostToDevice, s));
-        } else { // a cut-out of a much wider image: gathered rows from pinned memory of our own
-            WS_HIP(ctx, gather_rows(ctx->h_left, bgr));
-            WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, ctx->h_left.p, (size_t)width * 3 * height, hipMemcpyHostToDevice, s));
-        }
-    }
-    WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
-                                      static_cast<const uint8_t *>(ctx->d_left.p), bgr_stride, depth ? ddepth : nullptr, width,
-                                      positions ? dpos : nullptr, positions ? dcol : nullptr, input_is_depth, s));
-    if (depth)
-        WS_HIP(ctx, copy_rows(depth, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, s));
+    HostSpan sp[5];
+    sp[0].p = reinterpret_cast<uint8_t *>(const_cast<float *>(in)); sp[0].n = ((size_t)stride * (height - 1) + width) * 4; sp[0].stage = &ctx->h_out;
+    if (depth) { sp[1].p = reinterpret_cast<uint8_t *>(depth); sp[1].n = ((size_t)depth_stride * (height - 1) + width) * 4; sp[1].stage = &ctx->h_right; }
     if (positions) {
-        WS_HIP(ctx, hipMemcpyAsync(positions, dpos, n * 16, hipMemcpyDeviceToHost, s));
-        WS_HIP(ctx, hipMemcpyAsync(colors, dcol, n * 4, hipMemcpyDeviceToHost, s));
+        sp[2].p = reinterpret_cast<uint8_t *>(positions); sp[2].n = n * 16; sp[2].stage = &ctx->h_aux[0];
+        sp[3].p = colors; sp[3].n = n * 4; sp[3].stage = &ctx->h_aux[1];
     }
-    WS_HIP(ctx, hipStreamSynchronize(s));
-    return WS_OK;
+    if (lin_bgr) { sp[4].p = const_cast<uint8_t *>(bgr->data); sp[4].n = (size_t)bgr->stride * (height - 1) + (size_t)width * 3; sp[4].stage = &ctx->h_left; }
+    std::string note;
+    spans_attach(sp, 5, &note);
+    rc = [&]() -> int {
+        int rc2;
+        WS_HIP(ctx, span_upload_rows(sp[0], 0, (size_t)stride * 4, din, (size_t)width * 4, (size_t)height, s));
+        int bgr_stride = width * 3;
+        if (positions) { // the colour image as one linear copy with its own row stride (see ws_search_host)
+            if (lin_bgr) {
+                bgr_stride = bgr->stride;
+                if ((rc2 = ensure(ctx, ctx->d_left, sp[4].n)) != WS_OK) return rc2;
+                WS_HIP(ctx, span_upload(sp[4], 0, ctx->d_left.p, sp[4].n, s));
+            } else { // a cut-out of a much wider image: gathered rows from pinned memory of our own
+                WS_HIP(ctx, gather_rows(ctx->h_left, bgr));
+                WS_HIP(ctx, hipMemcpyAsync(ctx->d_left.p, ctx->h_left.p, (size_t)width * 3 * height, hipMemcpyHostToDevice, s));
+            }
+        }
+        WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
+                                          static_cast<const uint8_t *>(ctx->d_left.p), bgr_stride, depth ? ddepth : nullptr, width,
+                                          positions ? dpos : nullptr, positions ? dcol : nullptr, input_is_depth, s));
+        if (depth) WS_HIP(ctx, span_download(sp[1], 0, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)height, s));
+        if (positions) {
+            WS_HIP(ctx, span_download(sp[2], 0, n * 16, dpos, n * 16, 1, s));
+            WS_HIP(ctx, span_download(sp[3], 0, n * 4, dcol, n * 4, 1, s));
+        }
+        return WS_OK;
+    }();
+    const hipError_t es = hipStreamSynchronize(s);
+    const bool released = spans_finish(sp, 5, &note);
+    if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "depth / vertices: %s", hipGetErrorString(es));
+    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "depth / vertices: %s", note.c_str());
+    return rc;
 }
 
 int ws_convert_disparity_to_depth(ws_context *ctx, const float *disp, int width, int height, int stride, float focal_length,

@@ -1,3 +1,4 @@
+import faulthandler
 import glob
 import os
 import sys
@@ -11,9 +12,47 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# An abort must never again be "without a message" (round 2 lost two):
+#  * pytest.ini captures at sys level only, so the HIP runtime's own last words on fd 2 reach the log;
+#  * faulthandler (below, and pytest's own plugin) prints the Python traceback of the call that died on
+#    SIGABRT / SIGSEGV / SIGBUS to the real stderr;
+#  * the runtime logs its errors (AMD_LOG_LEVEL=1) to a file under gpurun_out/, whose tail is shown when a test
+#    fails and which survives the process when it does not get that far.
+AMD_LOG = os.path.join(ROOT, "gpurun_out", "amd_runtime_errors_%d.txt" % os.getpid())
+if "AMD_LOG_LEVEL" not in os.environ:
+    try:
+        os.makedirs(os.path.dirname(AMD_LOG), exist_ok=True)
+        os.environ["AMD_LOG_LEVEL"] = "1"
+        os.environ["AMD_LOG_LEVEL_FILE"] = AMD_LOG
+    except OSError:
+        pass
+faulthandler.enable(file=sys.__stderr__, all_threads=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _amd_log_tail(lines=25):
+    for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "amd_runtime_errors_%d.txt*" % os.getpid()))):
+        try:
+            with open(path, errors="replace") as f:
+                tail = f.readlines()[-lines:]
+        except OSError:
+            continue
+        if tail:
+            return "".join(tail)
+    return ""
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == "call" and rep.failed and item.get_closest_marker("gpu"):
+        tail = _amd_log_tail()
+        if tail:
+            rep.sections.append(("HIP runtime errors (AMD_LOG_LEVEL=1, last lines)", tail))
 
 
 def golden_cases():

@@ -1,0 +1,254 @@
+"""How caller buffers cross at the boundary (ws_search_host / ws_enqueue_host ... ws_wait; they replace the host-only
+ImageRectifier::computeDisparityMapLeft/Right, rectification.cpp:66-88, whose cv::Mat buffers are ordinary pageable
+memory).  Every shape here is one a real caller produces and one of them ended the process in round 2: the runtime
+aborts on hipHostUnregister of a pointer that is not a key of its host-allocation map but lies inside another registered
+range (tools/ubench/hostreg_probe.hip, profiles/r03/hostreg_probe.txt).  The library now registers disjoint page-aligned
+ranges only, shares them by reference count, leaves caller-pinned memory alone and stages what it cannot register;
+ws_last_host_paths says which way the bytes went.  Results must be the oracle's, bit for bit, whichever way.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from stereo_reconstruction_amd.synthetic import make_pair
+
+pytestmark = pytest.mark.gpu
+
+BS, MAXD = 7, 40
+
+
+def own_pages(a):
+    """A copy of `a` (or an empty array of that shape / dtype) that shares no page with any other allocation: small
+    numpy arrays come from the heap, where neighbours share pages and the library would (rightly) register them as
+    one hull or find them inside a live range -- the tests that assert WHICH way bytes crossed need to rule that out."""
+    a = np.asarray(a)
+    raw = np.empty(a.nbytes + 8192, dtype=np.uint8)
+    start = (-raw.ctypes.data) % 4096
+    out = raw[start:start + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def image(ws, a, width=None, height=None):
+    """ws_image over a (possibly strided) uint8 array view."""
+    h = a.shape[0] if height is None else height
+    w = a.shape[1] if width is None else width
+    return ws._Image(a.ctypes.data, w, h, a.strides[0])
+
+
+def host_call(ws, ctx, p, L, R, out, out_stride=None):
+    lib = ws.load_library()
+    Li, Ri = image(ws, L), image(ws, R)
+    code = 1 if out.dtype == np.float64 else 0
+    rc = lib.ws_search_host(ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), out.ctypes.data,
+                            out.shape[1] if out_stride is None else out_stride, code)
+    assert rc == 0, lib.ws_last_error(ctx._h)
+    return ctx.last_host_paths()
+
+
+def test_pageable_numpy_buffers_are_registered_for_the_call(wslib, gpu_ctx, oracle):
+    left, right, _ = make_pair(300, 120, MAXD, seed=301)
+    want = oracle.block_left(left, right, BS, 0, MAXD)
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+    out = np.empty((120, 300))
+    assert host_call(wslib, gpu_ctx, p, left, right, out) == ("registered",) * 3
+    assert np.array_equal(out, want)
+    # the same buffers again, and fresh ones at recycled addresses with other sizes
+    for h in (120, 90, 120, 60):
+        l2, r2, o2 = left[:h].copy(), right[:h].copy(), np.empty((h, 300))
+        assert host_call(wslib, gpu_ctx, p, l2, r2, o2) == ("registered",) * 3
+        assert np.array_equal(o2, oracle.block_left(l2, r2, BS, 0, MAXD))
+
+
+def test_left_and_right_cut_from_one_array_share_one_registration(wslib, gpu_ctx, oracle):
+    """Side-by-side stereo frames: both views are column ranges of ONE array, their byte spans interleave.  Round 2
+    registered the first, failed on the second and copied it 'unregistered'; the runtime refuses a copy that starts
+    inside a registered range and runs past its end (hipErrorInvalidValue)."""
+    left, right, _ = make_pair(260, 100, MAXD, seed=302)
+    frame = np.concatenate([left, right], axis=1)                    # H x 2W x 3
+    L, R = frame[:, :260], frame[:, 260:]
+    assert not L.flags["C_CONTIGUOUS"] and L.strides[0] == 2 * 260 * 3
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+    out = np.empty((100, 260), dtype=np.float32)
+    assert host_call(wslib, gpu_ctx, p, L, R, out) == ("registered",) * 3
+    assert np.array_equal(out.astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
+    # output rows inside the same allocation as the images (a struct-of-frames buffer)
+    blob = np.zeros(frame.nbytes + 100 * 260 * 4 + 64, dtype=np.uint8)
+    blob[:frame.nbytes] = frame.reshape(-1)
+    f2 = blob[:frame.nbytes].reshape(frame.shape)
+    o2 = blob[frame.nbytes + 64 - (blob.ctypes.data + frame.nbytes) % 64:][:100 * 260 * 4].view(np.float32).reshape(100, 260)
+    assert host_call(wslib, gpu_ctx, p, f2[:, :260], f2[:, 260:], o2) == ("registered",) * 3
+    assert np.array_equal(o2.astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
+
+
+def test_tiny_buffers_on_one_page(wslib, gpu_ctx, oracle):
+    left, right, _ = make_pair(24, 12, 6, seed=303)
+    slab = np.zeros(4096 * 3, dtype=np.uint8)
+    a = slab[100:100 + left.nbytes].reshape(left.shape)
+    b = slab[100 + left.nbytes + 7:100 + left.nbytes + 7 + right.nbytes].reshape(right.shape)
+    a[...], b[...] = left, right
+    out = slab[100 + 2 * left.nbytes + 64:]
+    out = out[(-out.ctypes.data) % 8:][:12 * 24 * 8].view(np.float64).reshape(12, 24)
+    p = wslib.make_params(wslib.VIEW_LEFT, 3, 0, 6, 1.0, "sad")
+    assert host_call(wslib, gpu_ctx, p, a, b, out) == ("registered",) * 3
+    assert np.array_equal(out, oracle.block_left(left, right, 3, 0, 6, cost="sad"))
+
+
+def test_caller_pinned_memory_is_used_as_it_is(wslib, gpu_ctx, oracle):
+    """Buffers the caller (here: PyTorch's pinned allocator) has pinned already are neither registered nor released by
+    the library; a whole hipHostMalloc'd block cannot be registered again anyway (hipErrorInvalidValue)."""
+    import torch
+    left, right, _ = make_pair(300, 120, MAXD, seed=304)
+    tl, tr = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    to = torch.empty((120, 300), dtype=torch.float32).pin_memory()
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+    assert host_call(wslib, gpu_ctx, p, tl.numpy(), tr.numpy(), to.numpy()) == ("caller-pinned",) * 3
+    assert np.array_equal(to.numpy().astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
+    # the blocks are still the allocator's: used and freed by their owner afterwards
+    assert torch.equal(tl.cuda().cpu(), tl)
+    del tl, tr, to
+    torch.cuda.synchronize()
+
+
+def test_a_range_the_caller_registered_in_part_goes_through_the_stage(wslib, gpu_ctx, oracle):
+    import torch
+    left, right, _ = make_pair(300, 120, MAXD, seed=305)
+    left, right = own_pages(left), own_pages(right)
+    rt = torch.cuda.cudart()
+    first = left[:60]                                                # the caller registers the upper half itself
+    assert int(rt.cudaHostRegister(first.ctypes.data, first.nbytes, 0)) == 0
+    try:
+        p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+        out = own_pages(np.empty((120, 300)))
+        how = host_call(wslib, gpu_ctx, p, left, right, out)
+        assert how[0] == "staged" and how[1] == "registered" and how[2] == "registered", how
+        assert np.array_equal(out, oracle.block_left(left, right, BS, 0, MAXD))
+        # in bands too (the stage is filled once, the bands upload from it), and as the output buffer
+        with wslib.WindowSearch(0) as ctx:
+            big_l, big_r, _ = make_pair(1100, 1000, 32, seed=306)
+            big_l, big_r = own_pages(big_l), own_pages(big_r)
+            assert int(rt.cudaHostRegister(big_l.ctypes.data, 4096 * 10, 0)) == 0
+            out2 = own_pages(np.empty((1000, 1100)))
+            assert int(rt.cudaHostRegister(out2.ctypes.data + 4096 * 100, 4096 * 3, 0)) == 0
+            try:
+                p2 = wslib.make_params(wslib.VIEW_LEFT, BS, 0, 32)
+                ctx.set_host_bands(4)
+                how = host_call(wslib, ctx, p2, big_l, big_r, out2)
+                assert how == ("staged", "registered", "staged"), how
+                ctx.set_host_bands(0)
+                plain = own_pages(np.empty((1000, 1100)))
+                assert host_call(wslib, ctx, p2, big_l, big_r, plain) == ("staged", "registered", "registered")
+                assert np.array_equal(out2, plain)
+                rows = (500, 540)
+                assert np.array_equal(plain[rows[0]:rows[1]], oracle.block_left(big_l, big_r, BS, 0, 32, rows=rows, threads=8)[rows[0]:rows[1]])
+            finally:
+                assert int(rt.cudaHostUnregister(big_l.ctypes.data)) == 0
+                assert int(rt.cudaHostUnregister(out2.ctypes.data + 4096 * 100)) == 0
+    finally:
+        assert int(rt.cudaHostUnregister(first.ctypes.data)) == 0
+
+
+def test_crops_of_one_image_in_a_batch(wslib, gpu_ctx, oracle):
+    """The sequence that ended the process in round 2: one base pointer under two sizes (two crops with the same
+    origin) inside a larger registration that starts below it (the whole image), all alive until ws_wait -- the
+    (pointer, size) registry registered the pointer twice and released it twice, and the runtime aborts on the second
+    release (profiles/r03/hostreg_probe.txt, 'twice-enclosed').  Plus a crop that overlaps a live range in part."""
+    lib = wslib.load_library()
+    left, right, _ = make_pair(320, 400, MAXD, seed=307)
+    left, right = own_pages(left), own_pages(right)
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+    crops = [(0, 400), (10, 110), (10, 210), (10, 110), (150, 400)]
+    outs, keep = [], []
+    for y0, y1 in crops:
+        L, R = left[y0:y1], right[y0:y1]                             # contiguous row ranges: same bytes, no copy
+        o = own_pages(np.empty((y1 - y0, 320), dtype=np.float32))
+        Li, Ri = image(wslib, L), image(wslib, R)
+        keep.append((L, R, Li, Ri))
+        outs.append(o)
+        assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), o.ctypes.data, 320, 0) == 0
+    # a buffer that starts inside the whole image's range and ends past it: cannot share, cannot be registered
+    # disjointly -> staged
+    tail = np.concatenate([left[300:], left[:50]])
+    joined = own_pages(np.concatenate([left, tail]))                 # its first 400 rows are `left` again
+    Lj, Rj = joined[:400], right
+    o_a = own_pages(np.empty((400, 320), dtype=np.float32))
+    o_b = own_pages(np.empty((100, 320), dtype=np.float32))
+    Lia, Ria = image(wslib, Lj), image(wslib, Rj)
+    assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Lia), ctypes.byref(Ria), o_a.ctypes.data, 320, 0) == 0
+    Ls, Rs = joined[350:450], own_pages(np.concatenate([right[350:], right[300:350]]))
+    Lib, Rib = image(wslib, Ls), image(wslib, Rs)
+    assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Lib), ctypes.byref(Rib), o_b.ctypes.data, 320, 0) == 0
+    assert lib.ws_wait(gpu_ctx._h) == 0
+    assert gpu_ctx.last_host_paths() == ("staged", "registered", "registered")
+    for (y0, y1), o in zip(crops, outs):
+        assert np.array_equal(o.astype(np.float64), oracle.block_left(left[y0:y1], right[y0:y1], BS, 0, MAXD)), (y0, y1)
+    assert np.array_equal(o_a.astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
+    assert np.array_equal(o_b.astype(np.float64), oracle.block_left(np.ascontiguousarray(Ls), Rs, BS, 0, MAXD))
+    # and single calls afterwards on the same buffers
+    assert np.array_equal(gpu_ctx.search(p, left, right), oracle.block_left(left, right, BS, 0, MAXD))
+
+
+def test_staged_maps_in_a_long_batch(wslib, gpu_ctx, oracle):
+    """Outputs that cannot be registered (the caller registered a page of each) come down through the job slots'
+    stages and are handed over before a slot is used again: more pairs than slots, padded output rows."""
+    import torch
+    lib = wslib.load_library()
+    rt = torch.cuda.cudart()
+    p = wslib.make_params(wslib.VIEW_RIGHT, BS, 0, MAXD, 1.0, "sad")
+    pairs = [make_pair(200, 90 + 8 * i, MAXD, seed=320 + i)[:2] for i in range(5)]
+    outs = [np.full((l.shape[0], 256), -7.0) for l, _ in pairs]
+    for o in outs:
+        assert int(rt.cudaHostRegister(o.ctypes.data + 4096, 4096, 0)) == 0
+    try:
+        keep = []
+        for (l, r), o in zip(pairs, outs):
+            Li, Ri = image(wslib, l), image(wslib, r)
+            keep.append((Li, Ri))
+            assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), o.ctypes.data, 256, 1) == 0
+        assert lib.ws_wait(gpu_ctx._h) == 0
+        assert gpu_ctx.last_host_paths()[2] == "staged"
+    finally:
+        for o in outs:
+            assert int(rt.cudaHostUnregister(o.ctypes.data + 4096)) == 0
+    for (l, r), o in zip(pairs, outs):
+        assert np.array_equal(o[:, :200], oracle.block_right(l, r, BS, 0, MAXD, cost="sad")) and (o[:, 200:] == -7.0).all()
+
+
+def test_an_error_in_the_middle_of_a_batch_leaves_nothing_behind(wslib, gpu_ctx, oracle):
+    """search_many used to drop its buffers when a pair was refused while earlier pairs were still copying from / into
+    them and their ranges stayed registered."""
+    left, right, _ = make_pair(300, 120, MAXD, seed=330)
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
+    bad = np.zeros((10, 10), dtype=np.uint8)                        # not an H x W x 3 image
+    with pytest.raises(ValueError):
+        gpu_ctx.search_many(p, [(left, right), (left, right), (bad, bad)])
+    even = wslib.make_params(wslib.VIEW_LEFT, 6, 0, MAXD)           # the reference throws: WS_ERR_GEOMETRY
+    with pytest.raises(wslib.WsError):
+        gpu_ctx.search_many(even, [(left, right)])
+    want = oracle.block_left(left, right, BS, 0, MAXD)
+    for o in gpu_ctx.search_many(p, [(left, right)] * 3, dtype=np.float64):
+        assert np.array_equal(o, want)
+    out = np.empty((120, 300))
+    assert host_call(wslib, gpu_ctx, p, left, right, out) == ("registered",) * 3 and np.array_equal(out, want)
+
+
+def test_consumers_take_pageable_and_partly_known_buffers(wslib, gpu_ctx):
+    import torch
+    rng = np.random.default_rng(9)
+    disp = rng.integers(1, 60, size=(200, 300)).astype(np.float32)
+    want = gpu_ctx.convert_disparity_to_depth(disp, 700.0, 0.2)
+    rt = torch.cuda.cudart()
+    d2 = disp.copy()
+    assert int(rt.cudaHostRegister(d2.ctypes.data + 8192, 4096, 0)) == 0
+    try:
+        assert np.array_equal(gpu_ctx.convert_disparity_to_depth(d2, 700.0, 0.2), want)
+        a = gpu_ctx.remove_disparity_outliers(disp, 9, 2.0, 3.0)
+        m = d2.copy()
+        lib = wslib.load_library()
+        padded = np.zeros((200, 320), dtype=np.float32)
+        padded[:, :300] = m
+        assert lib.ws_remove_disparity_outliers(gpu_ctx._h, padded.ctypes.data, 300, 200, 320, 9, 2.0, 3.0) == 0
+        assert np.array_equal(padded[:, :300], a) and (padded[:, 300:] == 0).all()
+    finally:
+        assert int(rt.cudaHostUnregister(d2.ctypes.data + 8192)) == 0

@@ -14,15 +14,6 @@ from conftest import ROOT, golden_cases, load_golden
 from stereo_reconstruction_amd.synthetic import make_pair
 
 
-def to_host(t):
-    """Device tensor -> numpy through pinned memory (these tests keep the runtime's pageable copy path out of a
-    process that registers host buffers elsewhere)."""
-    import torch
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t)
-    return h.numpy().copy()
-
-
 pytestmark = pytest.mark.gpu
 
 SUBPIXEL_TOL = 1e-4     # north_star: "within 1e-4 for float"
@@ -385,11 +376,11 @@ def test_strided_buffers_and_extreme_arguments(wslib, gpu_ctx, oracle):
     assert lib.ws_search_host(gpu_ctx._h, ctypes.byref(p3), ctypes.byref(CLi), ctypes.byref(CRi), o3.ctypes.data, 401, 0) == 0
     assert np.array_equal(o3.astype(np.float64), cwant)
     # the same through the device entry point with strided device tensors
-    tl, tr = torch.from_numpy(big_l).pin_memory().cuda()[5:55, 10:230], torch.from_numpy(big_r).pin_memory().cuda()[5:55, 10:230]
+    tl, tr = torch.from_numpy(big_l).cuda()[5:55, 10:230], torch.from_numpy(big_r).cuda()[5:55, 10:230]
     to = torch.full((50, 256), -5.0, dtype=torch.float32, device="cuda")
     gpu_ctx.search_device(p, tl, tr, to[:, :220], None)
     torch.cuda.synchronize()
-    assert np.array_equal(to_host(to)[:, :220].astype(np.float64), want) and bool((to[:, 220:] == -5.0).all())
+    assert np.array_equal(to.cpu().numpy()[:, :220].astype(np.float64), want) and bool((to[:, 220:] == -5.0).all())
     # a disparity range far wider than the image, and the largest window the ABI accepts
     l2, r2 = np.ascontiguousarray(left), np.ascontiguousarray(right)
     for view in ("left", "right"):
@@ -486,13 +477,13 @@ def test_errors_are_reported_not_computed(wslib, gpu_ctx):
 def test_device_resident_path_and_f32_output(wslib, gpu_ctx, oracle):
     import torch
     left, right, _ = make_pair(500, 120, 128, seed=4)
-    tl, tr = torch.from_numpy(left).pin_memory().cuda(), torch.from_numpy(right).pin_memory().cuda()
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     out = torch.full((120, 500), -7.0, dtype=torch.float32, device="cuda")
     p = wslib.make_params(wslib.VIEW_LEFT, 7, 0, 128, 1.0, "ssd")
     gpu_ctx.search_device(p, tl, tr, out, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = ref(oracle, "left", left, right, 7, 0, 128, "ssd")
-    assert np.array_equal(to_host(out).astype(np.float64), want)
+    assert np.array_equal(out.cpu().numpy().astype(np.float64), want)
     # deterministic: a second run on the library's own stream gives the same bits
     out2 = torch.empty_like(out)
     gpu_ctx.search_device(p, tl, tr, out2, None)
@@ -505,7 +496,7 @@ def test_device_entry_point_can_be_captured_into_a_hip_graph(wslib, gpu_ctx):
     caller's stream: a stream capture records it and the replay gives the same bits."""
     import torch
     left, right, _ = make_pair(500, 200, 64, seed=51)
-    tl, tr = torch.from_numpy(left).pin_memory().cuda(), torch.from_numpy(right).pin_memory().cuda()
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
     for view, s in ((wslib.VIEW_LEFT, 1.0), (wslib.VIEW_RIGHT, 0.9)):
         p = wslib.make_params(view, 7, 0, 64, s, "ssd")
         want = torch.empty((200, 500), dtype=torch.float32, device="cuda")
@@ -716,7 +707,7 @@ def test_calls_on_two_streams_share_the_scratch_safely(wslib, gpu_ctx, oracle):
     import torch
     pairs = [make_pair(640, 200, 96, seed=s)[:2] for s in (101, 102)]
     wants = [oracle.block_left(l, r, 7, 0, 96, threads=8) for l, r in pairs]
-    dev = [(torch.from_numpy(l).pin_memory().cuda(), torch.from_numpy(r).pin_memory().cuda()) for l, r in pairs]
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
     p = wslib.make_params(wslib.VIEW_LEFT, 7, 0, 96, 1.0, "ssd")
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     outs = [torch.empty((200, 640), dtype=torch.float32, device="cuda") for _ in range(8)]
@@ -725,7 +716,7 @@ def test_calls_on_two_streams_share_the_scratch_safely(wslib, gpu_ctx, oracle):
         gpu_ctx.search_device(p, dev[i & 1][0], dev[i & 1][1], o, streams[i & 1].cuda_stream)
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
-        assert np.array_equal(to_host(o).astype(np.float64), wants[i & 1]), i
+        assert np.array_equal(o.cpu().numpy().astype(np.float64), wants[i & 1]), i
 
 
 def test_var_block_texture_test_is_float32_like_opencv(wslib, gpu_ctx, oracle):

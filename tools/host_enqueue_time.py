@@ -5,7 +5,7 @@ import torch, stereo_reconstruction_amd as ws
 from stereo_reconstruction_amd.synthetic import make_pair
 w, h, D = 1500, 1000, 256
 L, R, _ = make_pair(w, h, D, 1)
-tl, tr = torch.from_numpy(L).pin_memory().cuda(), torch.from_numpy(R).pin_memory().cuda()
+tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 p = ws.make_params(ws.VIEW_LEFT, 7, 0, D, 1.0, "ssd")
 ctxs = [ws.WindowSearch(0) for _ in range(2)]
 outs = [torch.empty((h, w), dtype=torch.float32, device="cuda") for _ in range(2)]
