@@ -218,6 +218,13 @@ int ws_set_tuning(ws_context *ctx, int x_runs_per_tile, int strip_rows, int thre
  */
 int ws_set_host_bands(ws_context *ctx, int bands);
 /*
+ * ws_search_device only enqueues.  This waits for `stream` (NULL: the context's) and returns what the kernels
+ * flagged since the last check: WS_ERR_HIP if a band of the left view's smoothFactor raster pass
+ * (BlockSearch.cpp:68-73 in raster order) gave up waiting for the band above it -- the map is then not valid --
+ * else WS_OK.  The host entry points (ws_search_host, ws_wait) make the same check themselves.
+ */
+int ws_device_status(ws_context *ctx, void *stream);
+/*
  * How the bytes of the last host call's three buffers (left, right, out; for a batch: of its last pair) crossed:
  * 0 = not a linear span (gathered rows), 1 = registered by this library for the duration of the call, 2 = memory the
  * caller (or a framework) had pinned already, used as it is, 3 = through pinned staging memory of the library

@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libws_stereo.so")
-SOURCES = ["ws_march.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip", "ws_consumers.hip", "ws_capi.cpp"]
-HEADERS = [os.path.join(CSRC, "ws_kernels.h"), os.path.join(CSRC, "ws_device.h"),
+SOURCES = ["ws_march.hip", "ws_march_nd4.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip", "ws_consumers.hip", "ws_capi.cpp"]
+HEADERS = [os.path.join(CSRC, "ws_kernels.h"), os.path.join(CSRC, "ws_device.h"), os.path.join(CSRC, "ws_march_kernel.h"),
            os.path.join(HERE, "..", "include", "ws_stereo.h")]
 ARCH = "gfx950"
 
@@ -33,6 +33,9 @@ def stale():
 
 OBJ = os.path.join(HERE, "build")  # per-source objects (git-ignored): only what changed is compiled again
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# per-source flags: the 8-disparities-per-thread marching kernels keep their prefix chains interleaved under the
+# compiler's "max-ilp" scheduling strategy (ws_march_kernel.h)
+EXTRA = {"ws_march.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _object_stale(src, obj):
@@ -56,7 +59,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, name + ".o")
         objs.append(obj)
         if force or _object_stale(src, obj):
-            cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", src, "-o", obj + ".tmp.%d" % os.getpid()]
+            cmd = [hipcc()] + FLAGS + EXTRA.get(name, []) + ["-x", "hip", "-c", src, "-o", obj + ".tmp.%d" % os.getpid()]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             jobs.append((subprocess.Popen(cmd), obj))

@@ -384,8 +384,6 @@ struct RefineArgs {
     int d_lo, d_hi, b_lo, b_hi;
     int ox0, ox1, oy0, oy1;
     int ssd, centred, mirror;
-    const int32_t *bias; // SSD: the marching kernel's bias plane = (sum of b^2 over the window) << bias_shift
-    int pitch_bi, pad_bi, bias_shift;
     float *out;
     int out_pitch;
 };
@@ -404,17 +402,21 @@ __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs 
     if (d < g.d_lo || d > g.d_hi || xb < g.b_lo || xb > g.b_hi) return; // fallback value, not a match
     if (d - 1 < g.d_lo || d + 1 > g.d_hi || xb - 1 < g.b_lo || xb + 1 > g.b_hi) return;
     // costs at d-1 (target column +1), d, d+1 (target column -1); the three target windows overlap,
-    // so a row costs ww + 2 target loads, and for SSD the sums of b^2 are the bias plane's entries
+    // so a row costs ww + 2 target loads; for SSD the three sums of b^2 come from the same pixels (the marching
+    // kernel's bias plane carries a per-strip correction term besides them, ws_prepass.hip, and is not read here)
     long long cm = 0, c0 = 0, cp = 0;
     for (int r = 0; r < g.wh; ++r) {
         const uint32_t *pa = g.A + (size_t)(y + g.wy0 + r) * g.pitch_a + (x + g.wx0 + g.pad_a);
         const uint32_t *pb = g.B + (size_t)(y + g.wy0 + r) * g.pitch_b + (xb + g.wx0 + g.pad_b);
         uint32_t sm = 0, s0 = 0, sp = 0;
         uint32_t vp = pb[-1], v0 = pb[0];
+        uint32_t qt = 0; // SSD: sum of b^2 over pb[1 .. ww], the window of d - 1
+        const uint32_t q_m1 = SSD ? pix_dot<CENTRED>(vp, vp, 0u) : 0u, q_0 = SSD ? pix_dot<CENTRED>(v0, v0, 0u) : 0u;
         auto pixel = [&](int i) {
             const uint32_t a = pa[i], vm = pb[i + 1];
             if constexpr (SSD) {
                 sm = pix_dot<CENTRED>(a, vm, sm); s0 = pix_dot<CENTRED>(a, v0, s0); sp = pix_dot<CENTRED>(a, vp, sp);
+                qt = pix_dot<CENTRED>(vm, vm, qt);
             } else {
                 sm = pix_sad(a, vm, sm); s0 = pix_sad(a, v0, s0); sp = pix_sad(a, vp, sp);
             }
@@ -428,21 +430,19 @@ __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs 
             for (int i = 0; i < g.ww; ++i) pixel(i);
         }
         if constexpr (SSD) {
-            cm -= 2LL * (int32_t)sm; c0 -= 2LL * (int32_t)s0; cp -= 2LL * (int32_t)sp;
+            // (after the loop v0 = pb[ww], vp = pb[ww - 1]) windows: d - 1 = pb[1 .. ww], d = pb[0 .. ww - 1], d + 1 = pb[-1 .. ww - 2]
+            const uint32_t b0 = qt - pix_dot<CENTRED>(v0, v0, 0u) + q_0;
+            const uint32_t bp = b0 - pix_dot<CENTRED>(vp, vp, 0u) + q_m1;
+            cm += (long long)qt - 2LL * (int32_t)sm; c0 += (long long)b0 - 2LL * (int32_t)s0; cp += (long long)bp - 2LL * (int32_t)sp;
         } else {
             cm += sm; c0 += s0; cp += sp;
         }
-    }
-    if constexpr (SSD) {
-        const int32_t *bi = g.bias + (size_t)y * g.pitch_bi + (xb + g.pad_bi);
-        cm += bi[1] >> g.bias_shift; c0 += bi[0] >> g.bias_shift; cp += bi[-1] >> g.bias_shift;
     }
     const long long num = cm - cp, den = cm - 2 * c0 + cp;
     if (den > 0) *o = *o + (float)((double)num / (2.0 * (double)den));
 }
 
-hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias, float *out, int out_pitch,
-                                hipStream_t s)
+hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &, Plane a, Plane b, float *out, int out_pitch, hipStream_t s)
 {
     RefineArgs g{};
     g.A = a.data; g.B = b.data;
@@ -451,8 +451,6 @@ hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, P
     g.d_lo = c.d_lo; g.d_hi = c.d_hi; g.b_lo = c.b_lo; g.b_hi = c.b_hi;
     g.ox0 = c.ox0; g.ox1 = c.ox1; g.oy0 = c.oy0; g.oy1 = c.oy1;
     g.ssd = c.ssd; g.centred = march_centred(c); g.mirror = c.mirror;
-    g.bias = reinterpret_cast<const int32_t *>(bias.data); g.pitch_bi = bias.pitch; g.pad_bi = bias.pad;
-    g.bias_shift = ilog2c(m.nd_per_thread);
     g.out = out; g.out_pitch = out_pitch;
     dim3 grid(ceil_div(c.ox1 - c.ox0, 256), c.oy1 - c.oy0);
     // (the window widths of the BASELINE configs with the sub-pixel extension get the compile-time form)

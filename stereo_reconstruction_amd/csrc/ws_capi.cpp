@@ -356,6 +356,7 @@ struct ws_context {
     hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
+    unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up)
     int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
     std::vector<HostSpan> batch_spans; // caller buffers of the pairs enqueued since the last ws_wait (released there)
     HostBuf h_left, h_right, h_out;    // ws_search_host: gathered rows of cut-out images (gather_rows), stages (HostSpan)
@@ -566,7 +567,7 @@ int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const 
         if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
         uint32_t *top3 = static_cast<uint32_t *>(ctx->top3.p);
         WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march ? &ctx->last_canon : nullptr,
-                                       ctx->last_pa, ctx->last_pb, s));
+                                       ctx->last_pa, ctx->last_pb, ctx->status_dev, s));
         return WS_OK;
     }
     const bool smooth = q.smooth_factor != 1.0 && q.view != WS_VIEW_LEFT && q.min_disparity == 0;
@@ -711,7 +712,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ctx->last_skip[2] = ga.skip_y0; ctx->last_skip[3] = ga.skip_y1;
     }
     if (p->subpixel) {
-        if (march) WS_HIP(ctx, launch_refine_planes(c, m, ring_a, ring_b, ring_bi, out, out_stride, s));
+        if (march) WS_HIP(ctx, launch_refine_planes(c, m, ring_a, ring_b, out, out_stride, s));
         WS_HIP(ctx, launch_refine(ga, s)); // the pixels outside the marching interior (all of them without it)
     }
     return WS_OK;
@@ -743,6 +744,15 @@ int out_dims(const ws_params *p, const ws_image *L, const ws_image *R, int *w, i
     *w = p->view == WS_VIEW_LEFT ? L->width : R->width;
     *h = p->view == WS_VIEW_LEFT ? L->height : R->height;
     return 0;
+}
+
+// What the kernels flagged since the last check (the streams that carried them are idle: the caller synchronised).
+int check_device_status(ws_context *ctx)
+{
+    if (!ctx->status_host || !ctx->status_host[0]) return WS_OK;
+    ctx->status_host[0] = 0;
+    return fail(ctx, WS_ERR_HIP, "the left view's smoothFactor raster pass gave up waiting for the band above it "
+                                 "(ws_smooth_left_bands_kernel): the map is not valid");
 }
 
 } // namespace
@@ -803,6 +813,13 @@ int ws_create(int device, ws_context **out)
         return WS_ERR_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&ctx->status_host), 64, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->status_host, 0)) != hipSuccess) {
+        fail(nullptr, WS_ERR_HIP, "ws_create: %s", hipGetErrorString(e));
+        ws_destroy(ctx);
+        return WS_ERR_HIP;
+    }
+    memset(ctx->status_host, 0, 64);
     *out = ctx;
     return WS_OK;
 }
@@ -839,6 +856,7 @@ void ws_destroy(ws_context *ctx)
         if (ctx->ev_band_up[i]) (void)hipEventDestroy(ctx->ev_band_up[i]);
         if (ctx->ev_band_done[i]) (void)hipEventDestroy(ctx->ev_band_done[i]);
     }
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk0) (void)hipEventDestroy(ctx->evk0);
@@ -971,7 +989,15 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     if (rc == WS_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
         return fail(ctx, WS_ERR_HIP, "banded host call: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
     if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "banded host call: %s", note.c_str());
-    return rc;
+    return rc == WS_OK ? check_device_status(ctx) : rc;
+}
+
+int ws_device_status(ws_context *ctx, void *stream)
+{
+    if (!ctx) return WS_ERR_ARG;
+    WS_HIP(ctx, hipSetDevice(ctx->device));
+    WS_HIP(ctx, hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : ctx->stream));
+    return check_device_status(ctx);
 }
 
 int ws_last_host_paths(const ws_context *ctx, int how[3])
@@ -1064,7 +1090,7 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     const bool released = spans_finish(sp, 3, &note);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "host call: %s", hipGetErrorString(es));
     if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "host call: %s", note.c_str());
-    return rc;
+    return rc == WS_OK ? check_device_status(ctx) : rc;
 }
 
 // The batched host path keeps two pairs in flight: while one is searched (context stream) the next
@@ -1187,7 +1213,7 @@ int ws_wait(ws_context *ctx)
     if (e1 != hipSuccess || e2 != hipSuccess)
         return fail(ctx, WS_ERR_HIP, "ws_wait: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "ws_wait: %s", note.c_str());
-    return rc;
+    return rc == WS_OK ? check_device_status(ctx) : rc;
 }
 
 static bool invert3x3(const double m[9], double out[9])

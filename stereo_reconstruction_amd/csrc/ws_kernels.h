@@ -52,6 +52,9 @@ struct MarchLaunch {
 bool march_supported(const Canon &c);
 // 1 if this SSD window needs centred (byte - 128) planes to keep its sums in 32 bits
 int march_centred(const Canon &c);
+// does the SSD marching kernel take the entering and the leaving row in one chain (the bias plane then carries the
+// correction term of the complemented leaving rows, per strip)
+bool march_fused(const Canon &c);
 // Fill the tiling for this problem (tuning values of 0 = automatic).
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out);
@@ -95,15 +98,15 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
 // Sub-pixel refinement (extension): parabola through the integer cost at d-1, d, d+1.
 hipError_t launch_refine(const GenericArgs &g, hipStream_t s);
 // the same for the marching interior, on the packed planes (launch_refine then skips g's skip rectangle)
-hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias, float *out, int out_pitch,
-                                hipStream_t s); // bias: the marching kernel's bias plane (SSD)
+hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, Plane b, float *out, int out_pitch, hipStream_t s);
 // smoothFactor != 1, right view / LinearSearch: g.out must hold the d >= 1 search result
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
 // smoothFactor in [0,1], left view: g.out holds the smoothFactor-1 result on entry
 // top3: smooth_left_top_bytes(w1, h1) of scratch, only read / written when s is outside [0,1]
+// gave_up: host-visible word (device pointer) a band of the raster pass sets when it gave up waiting (the map is then invalid)
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
-                              hipStream_t st);
+                              unsigned int *gave_up, hipStream_t st);
 size_t smooth_left_top_bytes(int w, int h);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);

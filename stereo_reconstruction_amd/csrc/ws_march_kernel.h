@@ -1,0 +1,471 @@
+// ws_march_kernel.h -- the marching kernel's template (device code), shared by the two translation units that
+// instantiate it: ws_march.hip (8 disparities per thread, compiled with the compiler's "max-ilp" scheduling strategy:
+// its two interleaved prefix chains then stay interleaved -- 13 instead of 70 s_nop in the 7 x 7 SSD step, no spills at
+// any window) and ws_march_nd4.hip (4 per thread, default strategy: max-ilp costs those kernels a few registers and
+// with them the 128-VGPR line that lets two workgroups share a CU).  Overview of the device code: ws_march.hip.
+#pragma once
+#include "ws_device.h"
+
+namespace wsamd {
+
+// ------------------------------------------------------------------------------------------
+// the marching kernel
+// ------------------------------------------------------------------------------------------
+struct MarchArgs {
+    const uint32_t *A;
+    const uint32_t *B;
+    const int32_t *bias; // SSD only
+    float *out;
+    double *out64; // if set: doubles here instead of floats to `out` (CV_64F output without a widening pass)
+    int pitch_a, pad_a, pitch_b, pad_b, pitch_bi, pad_bi, out_pitch;
+    int wa;
+    int nxr, nch;
+    int wx0, wy0, boff;
+    int d_lo, d_hi, b_lo, b_hi;
+    int d_top;     // d_lo + passes * chunks * ND - 1: the padded upper end of the range (SSD tie tags count from it)
+    int d_first;   // first disparity of chunk 0 in THIS launch (d_lo + pass * chunks * ND)
+    int pass_mode; // 0 = the only pass, 1 = first, 2 = middle, 3 = last of several d-group passes
+    void *keys;    // several passes: plane of the best keys so far (slot_t per pixel)
+    int keys_pitch;
+    int ox0, ox1, oy0, oy1;
+    int strip_rows, tiles, strips;
+    int prefer_large, mirror, fallback_neg;
+    int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
+    int32_t *cost_out; // optional (smoothFactor passes): the winner's cost, SSD without the sum of a^2
+    int cost_pitch;
+};
+
+// LDS row layout.  A thread reads runs of consecutive pixels starting at column X*r; with a
+// plain row-major row the 16 lanes that share a ds_read_b128 cycle sit 4*X bytes apart and fall
+// on every (X/4)-th bank group only.  So a row is stored as NREG = X/4 regions: region j holds
+// the quads (16-byte groups of 4 pixels) whose index is j mod NREG, densely.  Lane r's m-th quad
+// is then quad r + m/NREG of region m%NREG: consecutive lanes read consecutive 16-byte slots and
+// every read is conflict free.  `ro` = dwords per region.
+template <int NREG>
+__device__ __forceinline__ int lds_phys(int q, int ro)
+{
+    const int quad = q >> 2;
+    return (quad % NREG) * ro + (quad / NREG) * 4 + (q & 3);
+}
+
+// N consecutive logical dwords starting at a quad this thread's run starts with
+// (base = row + 4 * first quad index inside region 0).
+template <int N, int NREG>
+__device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *base, int ro)
+{
+    constexpr int Q = (N + 3) / 4;
+#pragma unroll
+    for (int m = 0; m < Q; ++m) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + (m % NREG) * ro + (m / NREG) * 4);
+        if (4 * m + 0 < N) dst[4 * m + 0] = v.x;
+        if (4 * m + 1 < N) dst[4 * m + 1] = v.y;
+        if (4 * m + 2 < N) dst[4 * m + 2] = v.z;
+        if (4 * m + 3 < N) dst[4 * m + 3] = v.w;
+    }
+}
+
+// Asynchronous HBM -> LDS copy of one row (n dwords, 16-byte aligned source) into the region
+// layout: global_load_lds_dwordx4, no VGPR staging.  The LDS address of an LDS-DMA is wave-uniform
+// base (M0) + lane * 16, so consecutive lanes fill consecutive quads of one region and each lane
+// fetches the quad that belongs there (the source address carries the permutation).
+//
+// The instruction is issued through inline assembly ON PURPOSE: for the builtin the compiler makes
+// every later LDS read of the wave wait for vmcnt(0) (it cannot know the copy fills a ring slot nobody
+// reads in this step), which exposes the copy's whole latency at the top of the arithmetic; here
+// nothing waits until the explicit dma_wait() in front of the step's barrier (A/B on one MI355X,
+// config 2: 171 -> 166 us).  Dealing the copies of a step to different waves, with scalar addressing,
+// measured SLOWER (186-191 us): the loop below leaves them all to the workgroup's first wave.
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// (row_lds: the LDS byte address of the row's first dword -- an integer, taken once per kernel from the shared-memory
+// base: a generic pointer cast to the LDS address space at every call carries a null check that one of the compiler's
+// scheduling strategies could not encode)
+template <int NREG>
+__device__ __forceinline__ void stage_row_async(uint32_t row_lds, int ro, const uint32_t *gsrc, int n, int tid, int nt)
+{
+    const int lane = tid & 63;
+    const int nquads = (n + 3) >> 2;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const int nidx = (nquads - j + NREG - 1) / NREG; // quads of this region
+        for (int idx = tid; idx < nidx; idx += nt) {
+            // M0 is written right in front of its use and put back behind it, inside one statement: the compiler keeps
+            // values of its own in M0 (LDS-DMA builtins, indexed register moves) and is not told otherwise -- M0 is a
+            // reserved register, a clobber of it is refused with a warning
+            const uint32_t la = __builtin_amdgcn_readfirstlane(row_lds + 4u * (uint32_t)(j * ro + 4 * (idx - lane)));
+            uint32_t saved_m0;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(saved_m0)
+                         : "v"(gsrc + 4 * (idx * NREG + j)), "s"(la)
+                         : "memory");
+        }
+    }
+}
+
+// One row entering (SIGN=+1) or leaving (SIGN=-1) the window of every (column, disparity) this
+// thread owns.
+//   SAD: V = (window sum << shift) + global tie tag          key = V
+//   SSD: V = local tie tag - (2 * cross sum << LT)           key = bias[xb] + V
+//        (bias = box sum of the squared target pixels << LT, or poison for an invalid centre)
+// With KEY the candidate keys are folded into best[] (signed min; equal costs go to the smaller
+// tag, i.e. to the disparity the reference's strict '<' keeps).
+#ifndef WS_FUSE
+#define WS_FUSE 1
+#endif
+constexpr bool kFuseSsd = WS_FUSE != 0; // build-time knob for A/B runs (tools/variants.py); the pre-pass follows it (march_fused)
+
+template <int X, int ND, int WW, bool SSD, bool KEY>
+__device__ __forceinline__ void march_load(uint32_t (&pa)[X + WW - 1], uint32_t (&pb)[X + WW + ND - 2], uint32_t (&bi)[X + ND - 1],
+                                           const uint32_t *runA, int ro_a, const uint32_t *runB, int ro_b,
+                                           const int32_t *runBias, int ro_bi)
+{
+    constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
+    lds_run<X + WW - 1, NREG>(pa, runA, ro_a);
+    lds_run<X + WW + ND - 2, NREGB>(pb, runB, ro_b);
+    if constexpr (KEY && SSD) lds_run<X + ND - 1, NREGB>(bi, reinterpret_cast<const uint32_t *>(runBias), ro_bi);
+}
+
+template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
+__device__ __forceinline__ void march_compute(int32_t (&V)[X][ND], int32_t (&best)[X], const uint32_t (&pa)[X + WW - 1],
+                                              const uint32_t (&pb)[X + WW + ND - 2], const uint32_t (&bi)[X + ND - 1], int shift)
+{
+    constexpr int NA = X + WW - 1;
+    // SAD accumulates +cost, SSD accumulates -2*cross: flip the sign of the update for SSD
+    constexpr bool ADD = ((SIGN > 0) != SSD);
+    // two disparities at a time: two independent prefix chains interleave in the issue stream
+    // (a v_dot4 needs a wait state before its result can feed the next v_dot4's accumulator)
+#pragma unroll
+    for (int j = 0; j < ND; j += 2) {
+        uint32_t S0[NA], S1[NA];
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const uint32_t b0 = pb[i - j + ND - 1], b1 = pb[i - j + ND - 2];
+            s0 = SSD ? pix_dot<CENTRED>(pa[i], b0, s0) : pix_sad(pa[i], b0, s0);
+            s1 = SSD ? pix_dot<CENTRED>(pa[i], b1, s1) : pix_sad(pa[i], b1, s1);
+            S0[i] = s0;
+            S1[i] = s1;
+        }
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            const uint32_t w0 = ADD ? S0[x + WW - 1] - (x ? S0[x - 1] : 0u) : (x ? S0[x - 1] : 0u) - S0[x + WW - 1];
+            const uint32_t w1 = ADD ? S1[x + WW - 1] - (x ? S1[x - 1] : 0u) : (x ? S1[x - 1] : 0u) - S1[x + WW - 1];
+            V[x][j] = (int32_t)((w0 << shift) + (uint32_t)V[x][j]);
+            V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
+            if constexpr (KEY) {
+                const int32_t k0 = SSD ? (int32_t)bi[x - j + ND - 1] + V[x][j] : V[x][j];
+                const int32_t k1 = SSD ? (int32_t)bi[x - j + ND - 2] + V[x][j + 1] : V[x][j + 1];
+                best[x] = min(best[x], min(k0, k1));
+            }
+        }
+    }
+}
+
+template <int X, int ND, int WW, bool SSD, bool CENTRED, int SIGN, bool KEY>
+__device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X],
+                                          const uint32_t *runA, int ro_a, const uint32_t *runB,
+                                          int ro_b, const int32_t *runBias, int ro_bi, int shift)
+{
+    uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], bi[X + ND - 1];
+    march_load<X, ND, WW, SSD, KEY>(pa, pb, bi, runA, ro_a, runB, ro_b, runBias, ro_bi);
+    march_compute<X, ND, WW, SSD, CENTRED, SIGN, KEY>(V, best, pa, pb, bi, shift);
+}
+
+// SSD, steady state: the row entering the window and the row leaving it in ONE prefix chain.  The chain can only add,
+// so the leaving row's reference pixels come complemented (qa = ~a): for plain bytes (255 - a) . b = 255 b - a . b, for
+// centred bytes (~a = -a - 1) (-a - 1) . b = -b - a . b (the 4th byte of b is 0 either way).  The chain's differences are
+// then  (cross sum of the entering row) - (cross sum of the leaving row) + K * (sum of the leaving row's target bytes
+// over the window), K = 255 or -1: the last term does not depend on the reference image, only on (row, target
+// column), and the pre-pass folds its running total over the rows that left the strip so far into the bias plane
+// (ws_prepass.hip, bias_strip: bias = (sum b^2 + 2 K E) << LT).  V and the bias wrap around in 32 bits by themselves,
+// their sum -- the key -- is exact.  One difference, one accumulate and one chain per step instead of two each:
+// 7.0 instead of 9.0 instructions per hypothesis in the steady state (+ X + WW - 1 v_not per thread and step).
+template <int X, int ND, int WW, bool CENTRED>
+__device__ __forceinline__ void march_fused_ssd(int32_t (&V)[X][ND], int32_t (&best)[X], const uint32_t (&pa)[X + WW - 1],
+                                                const uint32_t (&pb)[X + WW + ND - 2], const uint32_t (&qa)[X + WW - 1],
+                                                const uint32_t (&qb)[X + WW + ND - 2], const uint32_t (&bi)[X + ND - 1], int shift)
+{
+    constexpr int NA = X + WW - 1;
+#pragma unroll
+    for (int j = 0; j < ND; j += 2) {
+        uint32_t S0[NA], S1[NA];
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            s0 = pix_dot<CENTRED>(pa[i], pb[i - j + ND - 1], s0);
+            s1 = pix_dot<CENTRED>(pa[i], pb[i - j + ND - 2], s1);
+            s0 = pix_dot<CENTRED>(qa[i], qb[i - j + ND - 1], s0);
+            s1 = pix_dot<CENTRED>(qa[i], qb[i - j + ND - 2], s1);
+            S0[i] = s0;
+            S1[i] = s1;
+        }
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            const uint32_t w0 = (x ? S0[x - 1] : 0u) - S0[x + WW - 1]; // (V accumulates -2 * cross)
+            const uint32_t w1 = (x ? S1[x - 1] : 0u) - S1[x + WW - 1];
+            V[x][j] = (int32_t)((w0 << shift) + (uint32_t)V[x][j]);
+            V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
+            const int32_t k0 = (int32_t)bi[x - j + ND - 1] + V[x][j];
+            const int32_t k1 = (int32_t)bi[x - j + ND - 2] + V[x][j + 1];
+            best[x] = min(best[x], min(k0, k1));
+        }
+    }
+}
+
+template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false>
+__global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
+{
+    static_assert(X % 4 == 0 && ND % 4 == 0, "runs start on 16-byte quads");
+    constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
+    constexpr int LT = ilog2c(ND);
+    constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
+    constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
+    // merge slots: SSD (cost << LT | 7) : global tie tag as one signed 64-bit key, SAD the 32-bit key itself;
+    // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
+    typedef typename std::conditional<SSD, long long, int32_t>::type slot_t;
+    const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : (slot_t)INT_MAX;
+
+    extern __shared__ uint4 ws_smem4[];
+    uint32_t *smem = reinterpret_cast<uint32_t *>(ws_smem4);
+
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int tx = g.nxr * X, dt = g.nch * ND;
+    const int n_a = tx + WW - 1, n_b = tx + WW + dt - 2, n_bi = tx + dt - 1;
+    const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
+    const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
+    const int a_w = NREG * ro_a, b_w = NREGB * ro_b, bi_w = NREGB * ro_bi;
+    uint32_t *ringA = smem;
+    uint32_t *ringB = ringA + NR * a_w;
+    int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
+    slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t ldsA = (uint32_t)(uintptr_t)(lds_u32 *)smem; // LDS byte addresses of the three rings (stage_row_async)
+    const uint32_t ldsB = ldsA + 4u * (uint32_t)(NR * a_w), ldsBi = ldsB + 4u * (uint32_t)(NR * b_w);
+
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so ids b and b+8 share one.  Give every XCD a contiguous range of (strip, tile) pairs:
+    // the tiles of a strip overlap in the target-image columns they read and then hit the same L2.
+    const int nblk = gridDim.x; // padded to a multiple of 8 by the launcher
+    const int logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    if (logical >= g.tiles * g.strips) return; // uniform per workgroup
+    const int tile_x0 = g.ox0 + (logical % g.tiles) * tx;
+    const int ys = g.oy0 + (logical / g.tiles) * g.strip_rows;
+    const int ye = min(ys + g.strip_rows, g.oy1);
+    if (ys >= ye) return; // uniform per workgroup
+
+    const int dhi_t = g.d_first + dt - 1;
+    const uint32_t *gA = g.A + (tile_x0 + g.wx0 + g.pad_a);
+    const uint32_t *gB = g.B + (tile_x0 + g.wx0 + g.boff - dhi_t + g.pad_b);
+    const uint32_t *gBi = SSD ? reinterpret_cast<const uint32_t *>(g.bias) + (tile_x0 + g.boff - dhi_t + g.pad_bi) : nullptr;
+
+    for (int k = tid; k < 2 * tx; k += NT) slots[k] = kEmpty;
+
+    const int r = tid % g.nxr, c = tid / g.nxr;
+    const bool worker = c < g.nch;
+    // run starts (dword offset inside region 0): A at column X*r, B / bias at column X*r + ND*(nch-1-c)
+    const int ia = 4 * r;
+    const int ib = 4 * (((X / 4) * r + (ND / 4) * (g.nch - 1 - (worker ? c : 0))) / NREGB);
+    const int d0 = g.d_first + c * ND; // first disparity of this thread's chunk
+    const int shift = SSD ? LT + 1 : g.tag_bits;
+    // SSD merge: global tie tag = chunk tag | local tag (a multiple of ND, so one v_and_or builds it):
+    // the chunk's distance from the preferred end of the padded range [d_lo, d_top]
+    const int ctag = g.prefer_large ? g.d_top - d0 - (ND - 1) : d0 - g.d_lo;
+
+    int32_t V[X][ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int d = d0 + j;
+        if constexpr (SSD) {
+            // local tag: the preferred disparity of a tie gets the smaller tag
+            const int tag = g.prefer_large ? (ND - 1 - j) : j;
+            const int32_t init = (d <= g.d_hi) ? tag : (kPoison + tag);
+#pragma unroll
+            for (int x = 0; x < X; ++x) V[x][j] = init;
+        } else {
+            // global tag; both validity rules (d range, target centre range) fold into V
+            const int tag = g.prefer_large ? g.d_hi - d : d - g.d_lo;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                const int xb = tile_x0 + r * X + x - d + g.boff;
+                V[x][j] = (d <= g.d_hi && xb >= g.b_lo && xb <= g.b_hi) ? tag : kPoison;
+            }
+        }
+    }
+
+    const int ra0 = ys + g.wy0; // first window row of the first output row
+    const int nsteps = (ye - ys) + WH - 1;
+
+    // prologue: row ra0 (and the bias row of step 0 when the window is one row high)
+    stage_row_async<NREG>(ldsA, ro_a, gA + (size_t)ra0 * g.pitch_a, n_a, tid, NT);
+    stage_row_async<NREGB>(ldsB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
+    if (SSD && WH == 1)
+        stage_row_async<NREGB>(ldsBi, ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
+    dma_wait();
+    __syncthreads();
+
+    int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
+    int sub_slot = 2 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
+    // image row of the output flushed at step a (row ys + a - WH) sits in slot (a - WH - wy0) mod NR
+    int out_slot = ((-WH - g.wy0) % NR + NR) % NR;
+
+    // 1. hand the row finished in the previous step to HBM
+    auto flush = [&](int oi) __attribute__((always_inline)) {
+        const int y = ys + oi - 1;
+        slot_t *sl = slots + ((oi - 1) & 1) * tx;
+        const uint32_t *rowA = ringA + out_slot * a_w;
+        // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
+        const int k = tid - (NT - round_up_dev(tx, 64));
+        if (k >= 0 && k < tx) {
+            const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r]
+            slot_t key = sl[si];
+            sl[si] = kEmpty;
+            const int x = tile_x0 + k;
+            if (x < g.ox1 && g.pass_mode != 0) {
+                // disparity ranges too wide for one tile run as several d-group passes that
+                // meet in a plane of keys (same keys, same ordering: min is the merge)
+                slot_t *kp = static_cast<slot_t *>(g.keys) + (size_t)y * g.keys_pitch + x;
+                if (g.pass_mode != 1) key = min(key, *kp);
+                if (g.pass_mode != 3) *kp = key;
+            }
+            if (x < g.ox1 && (g.pass_mode == 0 || g.pass_mode == 3)) {
+                const int xo = g.mirror ? g.wa - 1 - x : x;
+                float val;
+                const bool none = SSD ? (int32_t)((long long)key >> 32) >= kValidKeyBound : (int32_t)key >= kValidKeyBound;
+                if (none) {
+                    val = g.fallback_neg ? -(float)xo : (float)xo;
+                } else {
+                    const int gtag = SSD ? (int)(uint32_t)key : ((int)key & ((1 << g.tag_bits) - 1));
+                    val = (float)(g.prefer_large ? (SSD ? g.d_top : g.d_hi) - gtag : g.d_lo + gtag);
+                }
+                // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
+                if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
+                if (g.out64) g.out64[(size_t)y * g.out_pitch + xo] = (double)val;
+                else g.out[(size_t)y * g.out_pitch + xo] = val;
+                if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
+                    int32_t cst;
+                    if constexpr (SSD) cst = (int32_t)((long long)key >> 32) >> LT;
+                    else cst = (int32_t)key >> g.tag_bits;
+                    g.cost_out[(size_t)y * g.cost_pitch + xo] = cst;
+                }
+            }
+        }
+    };
+
+    // One step = one image row down.  PHASE 0: warm-up (the window fills: rows enter, nothing comes out), 1: the
+    // strip's first output row (nothing leaves yet), 2: steady state (a row enters, a row leaves, a row comes out).
+    // Each phase is a loop of its own: with one loop and branches on the step number the compiler joined the three
+    // variants' running sums at the bottom of the body -- 64 v_mov per thread and step (13 % of the instructions).
+    auto step = [&](int a, auto phase) __attribute__((always_inline)) {
+        constexpr int PHASE = decltype(phase)::value;
+        const int oi = a - (WH - 1); // output row index inside the strip produced by this step
+        if constexpr (PHASE == 2) flush(oi);
+
+        // 2. start the copy of the next step's rows into the ring slot nobody reads this step
+        int nxt_slot = add_slot + 1;
+        if (nxt_slot == NR) nxt_slot = 0;
+        if (a + 1 < nsteps) {
+            stage_row_async<NREG>(ldsA + 4u * (uint32_t)(nxt_slot * a_w), ro_a, gA + (size_t)(ra0 + a + 1) * g.pitch_a, n_a, tid, NT);
+            stage_row_async<NREGB>(ldsB + 4u * (uint32_t)(nxt_slot * b_w), ro_b, gB + (size_t)(ra0 + a + 1) * g.pitch_b, n_b, tid, NT);
+            if (SSD && oi + 1 >= 0)
+                stage_row_async<NREGB>(ldsBi + 4u * (uint32_t)(((oi + 1) & 1) * bi_w), ro_bi,
+                                      gBi + (size_t)(ys + oi + 1) * g.pitch_bi, n_bi, tid, NT);
+        }
+
+        // 3. arithmetic
+        if (worker) {
+            int32_t best[X];
+#pragma unroll
+            for (int x = 0; x < X; ++x) best[x] = INT_MAX;
+            const uint32_t *addA = ringA + add_slot * a_w + ia, *addB = ringB + add_slot * b_w + ib;
+            const uint32_t *subA = ringA + sub_slot * a_w + ia, *subB = ringB + sub_slot * b_w + ib;
+            const int32_t *brow = biasr + (oi & 1) * bi_w + ib;
+            if constexpr (PHASE == 0) {
+                march_row<X, ND, WW, SSD, CENTRED, +1, false>(V, best, addA, ro_a, addB, ro_b, nullptr, 0, shift);
+            } else if constexpr (PHASE == 1) {
+                march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
+            } else if constexpr (SSD && kFuseSsd) { // row a enters and row a - WH leaves in one chain
+                uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2], bi[X + ND - 1];
+                march_load<X, ND, WW, true, true>(pa, pb, bi, addA, ro_a, addB, ro_b, brow, ro_bi);
+                lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
+                lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
+#pragma unroll
+                for (int i = 0; i < X + WW - 1; ++i) qa[i] = ~qa[i];
+                march_fused_ssd<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
+            } else {
+                march_row<X, ND, WW, SSD, CENTRED, -1, false>(V, best, subA, ro_a, subB, ro_b, nullptr, 0, shift);
+                march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
+            }
+            if constexpr (PHASE >= 1) {
+                slot_t *sl = slots + (oi & 1) * tx + r;
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    const int32_t bk = best[x];
+                    // no validity test here: a poisoned key is just a large one, the flush sorts it out
+                    if constexpr (SSD) {
+                        const uint32_t gtag = (uint32_t)(bk & (ND - 1)) | (uint32_t)ctag; // v_and_or_b32
+                        const long long key = (long long)(((unsigned long long)(uint32_t)(bk | (ND - 1)) << 32) | gtag);
+                        atomicMin(sl + x * g.nxr, key); // ds_min_i64, lanes on consecutive slots
+                    } else {
+                        atomicMin(sl + x * g.nxr, bk); // ds_min_i32
+                    }
+                }
+            }
+        }
+
+        dma_wait(); // the row copies issued at the top of this step have long landed
+        __syncthreads();
+        add_slot = nxt_slot;
+        if (++sub_slot == NR) sub_slot = 0;
+        if (++out_slot == NR) out_slot = 0;
+    };
+
+    int a = 0; // (nsteps >= WH: a strip has at least one row)
+    for (; a < WH - 1; ++a) step(a, std::integral_constant<int, 0>());
+    step(a++, std::integral_constant<int, 1>());
+    for (; a < nsteps; ++a) step(a, std::integral_constant<int, 2>());
+    flush(nsteps - (WH - 1)); // the last row
+}
+
+typedef void (*MarchFn)(const MarchArgs);
+struct MarchEntry {
+    int ww, wh, ssd, nd;
+    MarchFn fn;
+    MarchFn fn_cost; // the same kernel also writing the winners' costs (right-view window sizes only)
+    const char *name;
+};
+#ifndef WS_X
+#define WS_X 8
+#endif
+#ifndef WS_ND
+#define WS_ND 8
+#endif
+#ifndef WS_MAXT
+#define WS_MAXT 512
+#endif
+constexpr int kX = WS_X, kND = WS_ND, kMaxT = WS_MAXT; // build-time tuning (tools/variants.py)
+constexpr int kNDNarrow = 4;                           // the second instantiation of every window (march_nd)
+// the flush hands one output column to one thread (k < tx <= NT): that needs nxr * X <= round_up(nxr * nch, 64), which
+// nch >= 8 gives for X <= 8 only
+static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns with one pass of the workgroup: X <= 8 (nch >= 8)");
+
+#define WS_MARCH_ENTRY_ND(W, H, N, TAG)                                                                          \
+    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H TAG ">"}, \
+    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H TAG ">"}
+#define WS_MARCH_ENTRY_COST_ND(W, H, N, TAG)                                                                   \
+    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, ws_march_kernel<kX, N, W, H, false, kMaxT, true>, \
+     "ws_march_kernel<sad," #W "x" #H TAG ">"},                                                                \
+    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, ws_march_kernel<kX, N, W, H, true, kMaxT, true>,   \
+     "ws_march_kernel<ssd," #W "x" #H TAG ">"}
+// every window: left view bs x bs, right view (bs-1) x (bs-1)
+#define WS_MARCH_TABLE(N, TAG)                                                                                         \
+    WS_MARCH_ENTRY_ND(3, 3, N, TAG), WS_MARCH_ENTRY_ND(5, 5, N, TAG), WS_MARCH_ENTRY_ND(7, 7, N, TAG),                 \
+    WS_MARCH_ENTRY_ND(9, 9, N, TAG), WS_MARCH_ENTRY_ND(11, 11, N, TAG), WS_MARCH_ENTRY_ND(13, 13, N, TAG),             \
+    WS_MARCH_ENTRY_ND(15, 15, N, TAG), WS_MARCH_ENTRY_ND(17, 17, N, TAG), WS_MARCH_ENTRY_COST_ND(2, 2, N, TAG),        \
+    WS_MARCH_ENTRY_COST_ND(4, 4, N, TAG), WS_MARCH_ENTRY_COST_ND(6, 6, N, TAG), WS_MARCH_ENTRY_COST_ND(8, 8, N, TAG),  \
+    WS_MARCH_ENTRY_COST_ND(10, 10, N, TAG), WS_MARCH_ENTRY_COST_ND(12, 12, N, TAG),                                    \
+    WS_MARCH_ENTRY_COST_ND(14, 14, N, TAG), WS_MARCH_ENTRY_COST_ND(16, 16, N, TAG)
+
+// the 4-disparities-per-thread instantiations (ws_march_nd4.hip)
+const MarchEntry *march_table_narrow(int *count);
+
+} // namespace wsamd

@@ -61,7 +61,8 @@ __device__ __forceinline__ void pack_block(const PackArgs &g, int z, int bx, int
 }
 
 // ------------------------------------------------------------------------------------------
-// bias rows: poison for invalid B centres; for SSD the box-summed squares of B
+// bias rows (SSD): poison for invalid B centres, the box-summed squares of B, and -- for the fused
+// marching kernel -- the correction term of its complemented leaving rows
 // ------------------------------------------------------------------------------------------
 struct BiasArgs {
     const uint8_t *src; // the target image's bytes (the pack of the same launch may not have run yet)
@@ -70,34 +71,51 @@ struct BiasArgs {
     int pitch, pad; // the bias plane (own padding: its row copies must start 16-byte aligned)
     int ww, wh, wx0, wy0;
     int b_lo, b_hi, oy0, oy1;
-    int ssd, shift, centred;
+    int shift, centred;
+    int strip_rows;  // the marching kernel's strips: output rows [oy0 + s * strip_rows, ...)
+    int kmul;        // fused kernel: 2 K (510 for plain bytes, -2 for centred ones, 0: not fused), see march_fused_ssd
     int32_t *bias;
 };
 
-constexpr int kBiasRows = 16; // output rows per workgroup (8 / 16 / 32 measured at config 2: 16.3 / 14.6 / 15.5 us for the launch)
+constexpr int kBiasRows = 16; // output rows per chunk (8 / 16 / 32 measured at config 2 in round 2: 16.3 / 14.6 / 15.5 us for the launch)
 constexpr int kBiasMaxWh = 17; // tallest (and widest) window with a marching instantiation
+constexpr int kBiasStage = kBiasRows + kBiasMaxWh - 1;
 
-// Separable box filter of the squared target pixels: a workgroup (64 x 4 threads) owns 64 columns
-// x kBiasRows rows.  The squares of its pixels (+ window halo) go to LDS straight from the image
-// bytes, then the horizontal sums, then thread (tx, ty) slides the vertical sum down its quarter
-// of the strip.
-__device__ __forceinline__ void bias_block(const BiasArgs &g, int bx, int by, uint32_t (*raw)[64], uint32_t (*sq)[64 + kBiasMaxWh],
-                                           uint32_t (*hs)[64])
+struct BiasLds {
+    uint32_t raw[kBiasStage][64];              // the rows' bytes as aligned dwords; then the horizontal sums of the squares
+    uint32_t sq[kBiasStage][64 + kBiasMaxWh];  // squares of the pixels (3 channels summed)
+    uint32_t cs[kBiasStage][64 + kBiasMaxWh];  // channel sums of the pixels (fused kernel)
+    uint32_t hb[kBiasStage][64];               // their horizontal sums over the window
+};
+
+// A workgroup (64 x 4 threads) owns 64 columns of one STRIP of the marching kernel and walks down it in chunks of
+// kBiasRows output rows.  Per chunk: the squares (and channel sums) of its pixels + window halo go to LDS straight
+// from the image bytes, then the horizontal window sums, then thread (tx, ty) slides the vertical sum down its
+// quarter of the chunk.  The fused marching kernel (march_fused_ssd) leaves K * (sum over the window columns of the
+// target bytes of every row that LEFT the window since the strip's first step) in its running sums; the bias entry of
+// output row y carries 2 K E(y) with E(y) = that sum over the window rows of the strip above y's window, i.e. rows
+// [ys + wy0, y + wy0): a prefix down the strip, carried from chunk to chunk in a register (e0).  All modulo 2^32, like
+// the kernel's own sums; bias + V is exact.  Invalid centres carry the term too (poison + 2 K E): the kernel's V holds
+// it whether or not the candidate is valid.
+__device__ __forceinline__ void bias_strip(const BiasArgs &g, int bx, int strip, BiasLds &l)
 {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = bx * 64 + tx;
-    const int y0 = g.oy0 + by * kBiasRows;
-    const int y1 = min(y0 + kBiasRows, g.oy1);
     const int xb = col - g.pad;
     const bool in_plane = col < g.pitch;
     const bool centre_ok = in_plane && xb >= g.b_lo && xb <= g.b_hi;
-    if (g.ssd) {
-        const int nrows = (y1 - y0) + g.wh - 1, ncols = 64 + g.ww - 1;
-        const int xc0 = bx * 64 - g.pad + g.wx0; // canonical column of sq[.][0]
-        // the image columns behind sq[.][0 .. ncols): one contiguous byte range per row
-        const int ca = max(xc0, 0), cb = min(xc0 + ncols, g.wb); // canonical [ca, cb)
-        const int xs_lo = g.mirror ? g.wb - cb : ca;             // first image column of the range
-        constexpr int kMaxTrips = (kBiasRows + kBiasMaxWh - 1 + 3) / 4;
+    const int ys = g.oy0 + strip * g.strip_rows, ye = min(ys + g.strip_rows, g.oy1);
+    const int ncols = 64 + g.ww - 1;
+    const int xc0 = bx * 64 - g.pad + g.wx0; // canonical column of sq[.][0]
+    // the image columns behind sq[.][0 .. ncols): one contiguous byte range per row
+    const int ca = max(xc0, 0), cb = min(xc0 + ncols, g.wb); // canonical [ca, cb)
+    const int xs_lo = g.mirror ? g.wb - cb : ca;             // first image column of the range
+    uint32_t (*hs)[64] = l.raw;
+    uint32_t e0 = 0; // 2 K E of the chunk's first output row, this thread's column
+    for (int y0 = ys; y0 < ye; y0 += kBiasRows) {
+        const int y1 = min(y0 + kBiasRows, ye);
+        const int nrows = (y1 - y0) + g.wh - 1;
+        constexpr int kMaxTrips = (kBiasStage + 3) / 4;
         // (1) the rows' bytes as aligned dwords, every load of a thread in flight at once
         uint32_t ld[kMaxTrips];
 #pragma unroll
@@ -111,13 +129,14 @@ __device__ __forceinline__ void bias_block(const BiasArgs &g, int bx, int by, ui
                 if (tx < ndw) ld[t] = reinterpret_cast<const uint32_t *>(a0)[tx];    // byte stays inside its page
             }
         }
+        if (y0 > ys) __syncthreads(); // the previous chunk's sums are read
 #pragma unroll
         for (int t = 0; t < kMaxTrips; ++t) {
             const int k = ty + 4 * t;
-            if (k < nrows) raw[k][tx] = ld[t];
+            if (k < nrows) l.raw[k][tx] = ld[t];
         }
         __syncthreads();
-        // (2) squares of the pixels
+        // (2) squares and channel sums of the pixels
 #pragma unroll 4
         for (int k = ty; k < nrows; k += 4) {
             const int yy = y0 + g.wy0 + k;
@@ -125,49 +144,56 @@ __device__ __forceinline__ void bias_block(const BiasArgs &g, int bx, int by, ui
             const uint32_t sh0 = row_ok ? (uint32_t)(reinterpret_cast<uintptr_t>(g.src + (size_t)yy * g.stride + 3 * (size_t)xs_lo) & 3) : 0u;
             for (int cx = tx; cx < ncols; cx += 64) {
                 const int xc = xc0 + cx;
-                uint32_t v = 0;
+                uint32_t v = 0, c = 0;
                 if (row_ok && xc >= ca && xc < cb) {
                     const uint32_t off = sh0 + 3u * (uint32_t)(g.mirror ? cb - 1 - xc : xc - ca); // byte offset in raw[k]
-                    const uint32_t lo = raw[k][off >> 2], hi = raw[k][(off >> 2) + 1];
+                    const uint32_t lo = l.raw[k][off >> 2], hi = l.raw[k][(off >> 2) + 1];
                     const uint32_t px = (__builtin_amdgcn_alignbyte(hi, lo, off & 3u) & 0xffffffu) ^ g.xor_mask;
                     v = g.centred ? pix_dot<true>(px, px, 0u) : pix_dot<false>(px, px, 0u);
+                    c = g.centred ? pix_dot<true>(px, 0x00010101u, 0u) : pix_dot<false>(px, 0x00010101u, 0u);
                 }
-                sq[k][cx] = v;
+                l.sq[k][cx] = v;
+                l.cs[k][cx] = c;
             }
         }
         __syncthreads();
 #pragma unroll 4
         for (int k = ty; k < nrows; k += 4) {
-            uint32_t acc = 0;
+            uint32_t acc = 0, bcc = 0;
             if (g.ww == 7) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) acc += sq[k][tx + i];
+                for (int i = 0; i < 7; ++i) { acc += l.sq[k][tx + i]; bcc += l.cs[k][tx + i]; }
             } else {
 #pragma unroll 8
-                for (int i = 0; i < g.ww; ++i) acc += sq[k][tx + i];
+                for (int i = 0; i < g.ww; ++i) { acc += l.sq[k][tx + i]; bcc += l.cs[k][tx + i]; }
             }
             hs[k][tx] = acc;
+            l.hb[k][tx] = bcc;
         }
         __syncthreads();
-    }
-    if (!in_plane) return;
-    const int seg = kBiasRows / 4;
-    const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
-    if (ya >= yb) return;
-    int32_t *dst = g.bias + (size_t)ya * g.pitch + col;
-    if (!centre_ok || !g.ssd) {
-        const int32_t v = centre_ok ? 0 : kPoison;
-        for (int y = ya; y < yb; ++y, dst += g.pitch) *dst = v;
-        return;
-    }
-    uint32_t acc = 0;
+        // (3) down the chunk
+        const int seg = kBiasRows / 4;
+        const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
+        if (in_plane && ya < yb) {
+            int32_t *dst = g.bias + (size_t)ya * g.pitch + col;
+            uint32_t e = e0;
+            if (g.kmul)
+                for (int k = 0; k < ya - y0; ++k) e += (uint32_t)g.kmul * l.hb[k][tx];
+            uint32_t acc = 0;
+            if (centre_ok) {
 #pragma unroll 8
-    for (int k = 0; k < g.wh; ++k) acc += hs[ya - y0 + k][tx];
-#pragma unroll 8
-    for (int y = ya; y < yb; ++y, dst += g.pitch) {
-        *dst = (int32_t)(acc << g.shift);
-        const int k = y - y0;
-        if (y + 1 < yb) acc += hs[k + g.wh][tx] - hs[k][tx];
+                for (int k = 0; k < g.wh; ++k) acc += hs[ya - y0 + k][tx];
+            }
+#pragma unroll 4
+            for (int y = ya; y < yb; ++y, dst += g.pitch) {
+                const int k = y - y0;
+                *dst = centre_ok ? (int32_t)((acc + e) << g.shift) : (int32_t)((uint32_t)kPoison + (e << g.shift));
+                if (centre_ok && y + 1 < yb) acc += hs[k + g.wh][tx] - hs[k][tx];
+                if (g.kmul) e += (uint32_t)g.kmul * l.hb[k][tx];
+            }
+        }
+        if (g.kmul)
+            for (int k = 0; k < y1 - y0; ++k) e0 += (uint32_t)g.kmul * l.hb[k][tx];
     }
 }
 
@@ -189,13 +215,11 @@ struct PrepareArgs {
 
 __global__ void __launch_bounds__(256) ws_prepare_kernel(const PrepareArgs g)
 {
-    // static LDS bounds the occupancy of every role: the raw bytes ((64 + 16) * 3 + alignment slack
-    // < 256 per row) are dead once the squares exist, the horizontal sums reuse their space
-    __shared__ uint32_t raw[kBiasRows + kBiasMaxWh - 1][64];
-    __shared__ uint32_t sq[kBiasRows + kBiasMaxWh - 1][64 + kBiasMaxWh];
-    uint32_t (*hs)[64] = raw;
+    // static LDS bounds the occupancy of every role (37 KB: four workgroups a CU): the raw bytes ((64 + 16) * 3 +
+    // alignment slack < 256 per row) are dead once the squares exist, the horizontal sums reuse their space
+    __shared__ BiasLds lds;
     int b = blockIdx.x; // the longest-running workgroups first
-    if (b < g.n_bias) { bias_block(g.bias, b % g.bias_gx, b / g.bias_gx, raw, sq, hs); return; }
+    if (b < g.n_bias) { bias_strip(g.bias, b % g.bias_gx, b / g.bias_gx, lds); return; }
     b -= g.n_bias;
     if (b < g.n_pack[0]) { pack_block(g.pack, 0, b % g.pack_gx[0], b / g.pack_gx[0]); return; }
     b -= g.n_pack[0];
@@ -225,11 +249,13 @@ hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *s
         bi.pitch = bias.pitch; bi.pad = bias.pad;
         bi.ww = c.ww; bi.wh = c.wh; bi.wx0 = c.wx0; bi.wy0 = c.wy0;
         bi.b_lo = c.b_lo; bi.b_hi = c.b_hi; bi.oy0 = c.oy0; bi.oy1 = c.oy1;
-        bi.ssd = c.ssd; bi.shift = ilog2c(m.nd_per_thread); bi.centred = centred;
+        bi.shift = ilog2c(m.nd_per_thread); bi.centred = centred;
+        bi.strip_rows = m.strip_rows;
+        bi.kmul = march_fused(c) ? (centred ? -2 : 510) : 0;
         bi.bias = reinterpret_cast<int32_t *>(bias.data);
         if (c.ww > kBiasMaxWh || c.wh > kBiasMaxWh) return hipErrorInvalidValue;
         g.bias_gx = ceil_div(bias.pitch, 64);
-        g.n_bias = g.bias_gx * ceil_div(c.oy1 - c.oy0, kBiasRows);
+        g.n_bias = g.bias_gx * m.strips; // (a workgroup walks down one strip of the marching kernel)
     }
     if (generic) {
         g.generic = *generic;

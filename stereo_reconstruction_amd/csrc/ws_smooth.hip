@@ -450,6 +450,8 @@ struct SmoothLeftArgs {
     double s;
     float *out; // holds d1 on entry, the final map on exit
     int out_pitch;
+    int spin_limit;         // polls a band makes for a hand-off word before it gives up (kBandSpinLimit)
+    unsigned int *gave_up;  // host-visible word of the context: set when a band gave up (the map is then not valid)
 };
 
 __device__ __forceinline__ bool left_candidate_ok(const SmoothLeftArgs &g, int x, int d, int half)
@@ -756,7 +758,9 @@ __device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch
         if (r < rows) {
             const uint32_t *src = plane + (size_t)min(max(row0 + r, 0), plane_rows - 1) * pitch + c;
             const uint32_t dst = (uint32_t)(uintptr_t)(lds_u32 *)(slot + part * 64);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(dst) : "memory");
+            uint32_t saved_m0; // (M0 put back inside the statement: see stage_row_async in ws_march.hip)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(saved_m0) : "v"(src), "s"(dst) : "memory");
         }
     }
 }
@@ -771,7 +775,9 @@ __device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch
 // pace, 64 steps and a hand-off latency behind its predecessor -- the hand-off is off the critical path.
 // Band numbers are tickets drawn at start-up: a band's predecessor has then certainly started, whatever order
 // the workgroups are dispatched in.  A poll that never succeeds (it cannot, short of a bug) gives up after a
-// bounded number of tries and flags it instead of hanging the device.
+// bounded number of tries and flags it instead of hanging the device: in the scratch (ctrl[1]) and in a host-visible
+// word of the context that every synchronising boundary call checks (ws_capi.cpp: check_device_status; ws_device_status
+// for callers of ws_search_device).
 constexpr int kBandRows = 64;
 constexpr unsigned long long kEdgeNone = ~0ull;
 constexpr int kBandSpinLimit = 1 << 20;
@@ -828,9 +834,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         for (int spins = 0;; ++spins) {
             if (t == 0) w = __hip_atomic_load(&edge_in[xl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__builtin_amdgcn_ballot_w64(t == 0 && w == kEdgeNone)) break;
-            if (spins > kBandSpinLimit) {
+            if (spins > g.spin_limit) {
                 gave_up = true;
-                if (t == 0) atomicOr(&ctrl[1], 1u);
+                if (t == 0) {
+                    atomicOr(&ctrl[1], 1u);
+                    __hip_atomic_store(g.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the host checks it at its next synchronisation
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -954,9 +963,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
             for (int spins = 0; !gave_up; ++spins) { // (only if the band above fell behind: it was ahead at start-up)
                 const bool wait = t == 0 && in && w == kEdgeNone;
                 if (!__builtin_amdgcn_ballot_w64(wait)) break;
-                if (spins > kBandSpinLimit) {
+                if (spins > g.spin_limit) {
                     gave_up = true;
-                    if (t == 0) atomicOr(&ctrl[1], 1u);
+                    if (t == 0) {
+                        atomicOr(&ctrl[1], 1u);
+                        __hip_atomic_store(g.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -1089,9 +1101,16 @@ static size_t smooth_left_sync_bytes(int w, int h) { return 64 + ((size_t)h / kB
 size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h); }
 
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
-                              hipStream_t st)
+                              unsigned int *gave_up, hipStream_t st)
 {
     SmoothLeftArgs a{};
+    static const int spin_limit = [] {
+        const char *e = getenv("WS_BAND_SPIN_LIMIT"); // development knob: -1 makes every band below the first give up (tests)
+        return e ? atoi(e) : kBandSpinLimit;
+    }();
+    a.spin_limit = spin_limit;
+    a.gave_up = gave_up;
+    if (!gave_up) return hipErrorInvalidValue;
     if (canon) { // the marching kernel ran: its planes are the two images, one dword per pixel
         a.A = pa.data; a.B = pb.data;
         a.pitch_a = pa.pitch; a.pad_a = pa.pad; a.pitch_b = pb.pitch; a.pad_b = pb.pad;

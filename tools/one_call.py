@@ -9,5 +9,5 @@ tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 out = torch.empty((h, w), dtype=torch.float32, device="cuda")
 sub = len(sys.argv) > 9 and sys.argv[9] == "subpixel"
 p = ws.make_params({"left": 0, "right": 1, "linear": 2}[view], bs, mind, maxd, s, cost, subpixel=sub)
-for _ in range(5): ctx.search_device(p, tl, tr, out, None)
+for _ in range(int(os.environ.get("WS_CALLS", "5"))): ctx.search_device(p, tl, tr, out, None)
 torch.cuda.synchronize()

@@ -13,12 +13,13 @@ def build(specs):
     for spec in specs:
         parts = spec.split(",")
         x, nd, maxt = parts[:3]
-        extra = parts[3:]
-        out = os.path.join(VDIR, "libws_%s.so" % spec.replace(",", "_"))
+        extra = [e for e in parts[3:] if not e.startswith("-")]
+        flags = [f for e in parts[3:] if e.startswith("-") for f in e.split(" ")]   # e.g. "-mllvm -amdgpu-sched-strategy=max-ilp"
+        out = os.path.join(VDIR, "libws_%s.so" % "".join(ch if ch.isalnum() else "_" for ch in spec))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-DWS_X=" + x, "-DWS_ND=" + nd, "-DWS_MAXT=" + maxt] + ["-D" + e for e in extra] + [
+               "-DWS_X=" + x, "-DWS_ND=" + nd, "-DWS_MAXT=" + maxt] + ["-D" + e for e in extra] + flags + [
                "-Rpass-analysis=kernel-resource-usage", "-o", out,
-               ] + [os.path.join(CSRC, f) for f in ("ws_march.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip",
+               ] + [os.path.join(CSRC, f) for f in ("ws_march.hip", "ws_march_nd4.hip", "ws_prepass.hip", "ws_border.hip", "ws_smooth.hip",
                                                      "ws_consumers.hip", "ws_capi.cpp")]
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         if r.returncode != 0:
