@@ -11,12 +11,15 @@ waits for them and passes rank 0's JSON line through.
 A "step" is one pass of the hot path (BlockSearch::computeDisparityMapLeft,
 BlockSearch.cpp:24-86, through the C-ABI ws_search_device) over one BATCH of synthetic
 Middlebury-H-shaped pairs already resident in HBM: BASELINE.json configs[1]
-= 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0, 16 pairs per step (so that the
-few steps the driver times are tens of milliseconds of work), consecutive pairs on
-alternating contexts (--in-flight 2: one pair's pre-pass overlaps the other's search).
+= 1500x1000, 7x7 SSD, D=256, left view, smoothFactor 1.0, 704 pairs per step, every one with its
+own bytes in HBM (so that a step is ~0.1 s and the 20 steps the driver times are ~2 s of device
+work, visible to its utilisation sampler), consecutive pairs on alternating contexts
+(--in-flight 2: one pair's pre-pass overlaps the other's search).  `value_single_pair` is the
+like-for-like figure of one pair at a time on one context.
 With N ranks every rank owns its own batch (independent pairs shard with no collective:
 weak scaling); the barrier / all_reduce(MAX) below only brackets the timing.  `--workload config4` is
-BASELINE.json configs[3]: the 15 trainingH-shaped pairs sharded over the ranks (strong).
+BASELINE.json configs[3]: the 15 trainingH-shaped pairs cut into row bands of >= 256 rows and
+sharded over the ranks (strong; stereo_reconstruction_amd/sharding.py: band_items).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
 (ws_march_kernel): algorithmic bytes per launch / its average duration measured
@@ -38,13 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r02"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
+PROFILE_ROUND = "r03"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
 
-# A step is one pass of the hot path over one BATCH of pairs of the workload's shape (distinct images), so that
-# the few steps the driver times (20 after 5 of warm-up) are tens of milliseconds of device work: a 0.17 ms
-# pair timed 25 times in a row measures the clocks coming up, not the path (measured: 2.18e6 Mdisparities/s
-# over 5 + 50 single pairs, 2.33e6 over 50 + 200 and over 200 + 1000).
-PAIRS_PER_STEP = {"config2": 16, "config3": 4, "config5": 2, "config1": 64}
+# A step is one pass of the hot path over one BATCH of pairs of the workload's shape (distinct images, all resident
+# in HBM: 10.6 GB at config 2), sized so that a step is ~0.1 s: the 20 steps the driver times after 5 of warm-up are
+# then ~2 s of device work -- visible to a utilisation sampler, and long past the clocks coming up (a 0.17 ms pair
+# timed 25 times in a row measured them: 2.18e6 Mdisparities/s over 5 + 50 single pairs, 2.33e6 over 200 + 1000).
+PAIRS_PER_STEP = {"config2": 704, "config3": 112, "config5": 32, "config1": 4096}
+CONFIG4_REPEAT = 100   # config 4: a step is this many passes over the rank's row bands (>= 20 ms a step at 8 ranks)
 WORKLOADS = {
     # name: (width, height, block, cost, maxD, seed)
     "config2": (1500, 1000, 7, "ssd", 256, 2),
@@ -76,8 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e and quality legs (profiling runs)")
-    ap.add_argument("--cpu-rows", type=int, default=1000,
-                    help="rows of the all-cores CPU baseline sample (1/16 of it for the one-core sample)")
+    ap.add_argument("--cpu-rows", type=int, default=300,
+                    help="rows of the all-cores CPU baseline sample (1/16 of it for the one-core sample): ~4 s together")
     ap.add_argument("--check", action="store_true", help="compare a row band with the oracle")
     ap.add_argument("--pairs-per-step", type=int, default=0,
                     help="pairs a rank searches per step (its batch); 0 = the workload's default")
@@ -165,38 +169,47 @@ def main():
     ctx = ctxs[0] if ctxs else None
     batch = args.workload == "config4"
     if batch:
-        from stereo_reconstruction_amd.sharding import lpt_assign
+        from stereo_reconstruction_amd.sharding import band_items
         from stereo_reconstruction_amd.synthetic import TRAINING_H
         bs, cost, max_d = 7, "ssd", 256
+        half = (bs - 1) // 2
         shapes = [(w, h) for _, w, h, _ in TRAINING_H]
-        mine = lpt_assign([w * h * max_d for w, h in shapes], world)[rank]   # may be empty (world > 15)
-        todo = [(shapes[i][0], shapes[i][1], 100 + i) for i in mine]
-        hyps_total = float(sum(w * h * max_d for w, h in shapes))
+        items, shards = band_items(shapes, max_d, world, bs)          # (pair, y0, y1) row bands, >= 256 rows each
+        mine = shards[rank]                                           # may be empty (more ranks than bands)
+        todo = [(shapes[items[j][0]][0], shapes[items[j][0]][1], 100 + items[j][0]) for j in mine]
+        bands = [(items[j][1], items[j][2]) for j in mine]
+        hyps_total = float(sum(w * h * max_d for w, h in shapes)) * CONFIG4_REPEAT
         width, height = shapes[0]
         pps = 0
     else:
         width, height, bs, cost, max_d, seed = WORKLOADS[args.workload]
+        half = (bs - 1) // 2
         pps = args.pairs_per_step if args.pairs_per_step > 0 else PAIRS_PER_STEP[args.workload]
         mine = [rank * pps + i for i in range(pps)]
         todo = [(width, height, seed + rank)] * pps
+        bands = [(0, height)] * pps
         hyps_total = float(width) * height * max_d * pps * world   # the same batch per rank (weak scaling)
     host_pairs, pairs = [], []
     made = {}
     for k, (w, h, sd) in enumerate(todo):
+        y0, y1 = bands[k]
+        a, b = max(0, y0 - half), min(h, y1 + half)   # the band's sub-images: its map rows + the window's halo
         if dry:
             host_pairs.append((None, None))
-            pairs.append((w, h))
+            pairs.append((w, b - a))
             continue
         if (w, h, sd) not in made:
             l, r, _ = make_pair(w, h, max_d, sd)
             made[(w, h, sd)] = (l, r, torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev))
             host_pairs.append((l, r))
             tl, tr = made[(w, h, sd)][2:]
+        elif batch:
+            tl, tr = made[(w, h, sd)][2:]             # another band of a pair this rank already holds
         else:
             # further pairs of the batch: the same scene shifted down by a few rows (both views alike, so it
             # still is a rectified pair) -- different bytes in every buffer without a second of numpy per pair
             tl, tr = (torch.roll(t, 37 * k, 0).contiguous() for t in made[(w, h, sd)][2:])
-        pairs.append((tl, tr, torch.empty((h, w), dtype=torch.float32, device=dev)))
+        pairs.append((tl[a:b], tr[a:b], torch.empty((b - a, w), dtype=torch.float32, device=dev)))
     params = None if dry else ws.make_params(ws.VIEW_LEFT, bs, 0, max_d, 1.0, cost)
 
     def step():
@@ -205,8 +218,9 @@ def main():
             return
         # whole pairs per rank, no collective on the data path; consecutive pairs on alternating contexts
         # (each on its own stream, with its own scratch planes)
-        for k, (tl, tr, to) in enumerate(pairs):
-            ctxs[k % in_flight].search_device(params, tl, tr, to, None)
+        for _ in range(CONFIG4_REPEAT if batch else 1):
+            for k, (tl, tr, to) in enumerate(pairs):
+                ctxs[k % in_flight].search_device(params, tl, tr, to, None)
 
     def sync():
         if not dry:
@@ -224,6 +238,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    sync()
+    own_elapsed = time.perf_counter() - t0      # this rank's own work, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -235,16 +251,31 @@ def main():
 
     # dominant kernel, timed alone with HIP events on the launch stream: every pair of this rank
     reps = max(1, min(args.steps, 20))
-    kernel_ms = [0.0] * len(pairs)     # average duration of the marching kernel, per pair of this rank
+    sampled = pairs[:32]               # (a sample of the batch: every pair of it has the same shape, except config 4's)
+    if batch:
+        sampled = pairs
+    kernel_ms = [0.0] * len(sampled)   # average duration of the marching kernel, per sampled pair of this rank
     info = {"kernel": "", "threads": 0, "workgroups": 0, "lds_bytes": 0}
+    single_pair_ms = None
     if not dry and pairs:
         ctx.set_profiling(True)
         for _ in range(reps):
-            for i, (tl, tr, to) in enumerate(pairs):
+            for i, (tl, tr, to) in enumerate(sampled):
                 ctx.search_device(params, tl, tr, to, None)   # one pair at a time: the kernel alone on the device
                 kernel_ms[i] += ctx.last_kernel_ms() / reps
         ctx.set_profiling(False)
         info = ctx.last_launch()
+        if not batch:
+            # the like-for-like figure of earlier rounds: ONE context, one pair after the other (what --in-flight 1
+            # times), after all of the above as warm-up
+            n1 = max(64, min(len(pairs), int(0.3 / max(1e-6, sum(kernel_ms) / len(kernel_ms) * 1e-3))))
+            sync()
+            t1 = time.perf_counter()
+            for i in range(n1):
+                tl, tr, to = pairs[i % len(pairs)]
+                ctx.search_device(params, tl, tr, to, None)
+            sync()
+            single_pair_ms = (time.perf_counter() - t1) / n1 * 1e3
     # ... and the way the timed region runs it: with the other context's pair beside it (the last launch of
     # every context in each of a few steps; the events sit on the launch streams and nothing waits inside a step)
     kernel_ms_in_flight = None
@@ -252,15 +283,19 @@ def main():
         for c in ctxs:
             c.set_profiling(True)
         samples = []
-        for _ in range(reps):
+        for _ in range(min(reps, 3)):
             step()
             samples.extend(c.last_kernel_ms() for c in ctxs)
         for c in ctxs:
             c.set_profiling(False)
         kernel_ms_in_flight = sum(samples) / len(samples)
-    alg_bytes = [3.0 * h * w + 3.0 * h * w + 4.0 * h * w for (w, h, _) in todo]   # both images + the f32 map
-    summary = {"rank": rank, "pairs": list(mine), "kernel_ms_sum": round(sum(kernel_ms), 4),
-               "alg_bytes": sum(alg_bytes), "hyps": float(sum(w * h * max_d for w, h, _ in todo))}
+    # both images + the f32 map of what was sampled (config 4: the rank's bands incl. their halo rows)
+    rows_of = [(min(h, y1 + half) - max(0, y0 - half)) for (w, h, _), (y0, y1) in zip(todo, bands)][:len(sampled)]
+    alg_bytes = [10.0 * rows * w for rows, (w, h, _) in zip(rows_of, todo)]
+    summary = {"rank": rank, "pairs": list(mine)[:len(sampled)], "kernel_ms_sum": round(sum(kernel_ms), 4),
+               "alg_bytes": sum(alg_bytes), "hyps": float(sum(rows * w * max_d for rows, (w, h, _) in zip(rows_of, todo))),
+               "items": len(pairs), "wall_ms": round(own_elapsed * 1e3, 3),
+               "map_hyps": float(sum((y1 - y0) * w * max_d for (w, h, _), (y0, y1) in zip(todo, bands)))}
     if dist is not None:
         summaries = [None] * world
         dist.all_gather_object(summaries, summary)
@@ -286,7 +321,7 @@ def main():
                     # the bound that actually applies: VALU instruction issue
                     lane_ops = tj["sq_insts_valu"] * 64.0
                     per_launch_ms = k_ms / n_launch
-                    valu = {"lane_ops_per_launch": lane_ops,
+                    valu = {"from_profiles": True, "lane_ops_per_launch": lane_ops,
                             "lane_ops_per_hypothesis": round(lane_ops / (busiest["hyps"] / n_launch), 2),
                             "achieved_lane_ops_per_s": round(lane_ops / (per_launch_ms * 1e-3), 0),
                             "measured_issue_peak_lane_ops_per_s": tj["valu_issue_peak_lane_ops_per_s"],
@@ -306,25 +341,34 @@ def main():
             "dtype": "u8",
             "data": "synthetic" + ((" (REHEARSAL: %s)" % ("no device, stand-in step" if dry else "ranks share GPUs, gloo"))
                                    if rehearse else ""),
-            "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs sharded over the ranks (LPT), left view, "
-                                    "%dx%d %s, D=%d, smoothFactor 1.0" % (bs, bs, cost.upper(), max_d)) if batch else
+            "config": {"workload": ("config4: 15 trainingH-shaped BGR pairs in row bands of >= 256 rows sharded over the ranks "
+                                    "(equal-weight runs of rows), %d passes per step, left view, %dx%d %s, D=%d, "
+                                    "smoothFactor 1.0" % (CONFIG4_REPEAT, bs, bs, cost.upper(), max_d)) if batch else
                                    "%s: a batch of %d %dx%d BGR pairs per GPU and step, left view, %dx%d %s, D=%d, smoothFactor 1.0"
                                    % (args.workload, pps, width, height, bs, bs, cost.upper(), max_d),
-                       "pairs_per_step": 15 if batch else pps * world, "in_flight_per_gpu": in_flight,
-                       "sharding": "independent pairs, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                       "pairs_per_step": 15 * CONFIG4_REPEAT if batch else pps * world, "in_flight_per_gpu": in_flight,
+                       "sharding": "row bands of independent pairs, no collective" if batch else "independent pairs, no collective"},
+            # `bound`: what binds the kernel (VALU instruction issue: D/10 hypotheses per compulsory byte); achieved /
+            # peak / frac are the HBM figures the contract asks for: algorithmic bytes per launch / kernel time
+            "roofline": {"bound": "valu_issue", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_from_profiles": None if traffic is None else "profiles/%s/traffic_%s.json (rocprofv3 --pmc passes of the "
+                                                  "committed kernels, not collected in this run)" % (PROFILE_ROUND, args.workload),
                          "kernel": info["kernel"], "kernel_ms": round(k_ms / n_launch, 4),
                          "kernel_ms_in_flight": None if kernel_ms_in_flight is None else round(kernel_ms_in_flight, 4),
-                         "launches": n_launch, "algorithmic_bytes": k_bytes / n_launch, "valu_issue": valu,
+                         "launches": n_launch, "algorithmic_bytes": k_bytes / n_launch, "valu_issue_from_profiles": valu,
                          "note": "stencil/reduction with D/10 hypotheses per compulsory byte: VALU-issue bound, see "
                                  "DESIGN.md for the lane-op ceiling; kernel_ms / achieved: the kernel alone on the "
                                  "device, kernel_ms_in_flight: a launch of the timed region, sharing the chip with "
                                  "the other context's pair (a rocprofv3 average of the default command mixes both)"},
         }
+        if single_pair_ms is not None:
+            out["value_single_pair"] = round(float(width) * height * max_d / single_pair_ms / 1e3, 1)
+            out["single_pair"] = {"ms_per_pair": round(single_pair_ms, 4), "what": "one context, one pair after the other "
+                                  "(--in-flight 1 semantics; BENCH_r01 timed this way), after the timed region as warm-up"}
         if batch or world > 1:
-            out["per_rank"] = [{"rank": s["rank"], "pairs": len(s["pairs"]), "kernel_ms_sum": s["kernel_ms_sum"],
-                                "Mdisp": round(s["hyps"] / 1e6, 1)} for s in summaries]
+            out["per_rank"] = [{"rank": s["rank"], "items": s["items"], "kernel_ms_sum": s["kernel_ms_sum"],
+                                "wall_ms": s["wall_ms"], "Mdisp_map": round(s["map_hyps"] / 1e6, 1)} for s in summaries]
 
     single = rank == 0 and world == 1 and not dry
     left, right = host_pairs[0] if host_pairs else (None, None)

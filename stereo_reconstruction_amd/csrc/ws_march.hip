@@ -36,6 +36,8 @@
 // DESIGN.md.  Wave64 throughout; nothing here assumes 32-wide warps.
 #include "ws_march_kernel.h"
 
+#include <string.h>
+
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -52,36 +54,75 @@ constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1
 // pairs alternately, INTEGRATION.md -- share a CU.  The table behind march_nd's rule: profiles/r03/nd_grid.txt.
 static const MarchEntry kMarchWide[] = {WS_MARCH_TABLE(kND, "")};
 
-// disparities per thread for this search: a function of the canonical problem alone, so that everything that
-// reads the marching kernel's planes afterwards (smoothFactor, sub-pixel refine) derives the same key layout
-static int march_nd(const Canon &c)
+// The thread shapes a search can run with: X columns x ND disparities per thread.
+struct MarchShape { int x, nd; };
+constexpr MarchShape kShapeWide{kX, kND}, kShapeNarrow{kX, kNDNarrow};
+static bool same_shape(MarchShape a, MarchShape b) { return a.x == b.x && a.nd == b.nd; }
+static int min_chunks(MarchShape s) { return s.x > 8 ? s.x : 8; } // (the flush needs nch >= X, ws_march_kernel.h)
+// d-chunks a tile holds at most: 64 (512 disparities with 8 per thread; more would leave too few columns per tile);
+// a shape with more than 8 columns per thread would keep 4 x-runs with 128 chunks
+static int max_chunks(MarchShape s) { return s.x > 8 ? kMaxT / kMinXRuns : kMaxChunks; }
+
+// Row times a search would take with a thread shape, in units of one row step of the 8 x 8 kernel, on a chip of 256
+// CUs with one workgroup per CU at a time -- the strip planner's own model (march_plan): the chip works through
+// ceil(workgroups / CUs) rounds of strips, a strip of R rows costs R + (wh - 1) / 2 + 3 row steps.  A row step of the
+// 8 x 4 kernel covers half the hypotheses per workgroup and costs 0.62 of an 8 x 8 one (measured: 1.19 .. 1.29 times the
+// time per hypothesis over windows 5 .. 17 at D = 512, profiles/r03/nd_grid.txt).
+static double march_model_cost(const Canon &c, MarchShape sh)
 {
-    static const int forced = [] {
-        const char *e = getenv("WS_MARCH_ND"); // development knob
-        const int v = e ? atoi(e) : 0;
-        return v == kND || v == kNDNarrow ? v : 0;
-    }();
-    if (forced) return forced;
-    if (kND == kNDNarrow) return kND;
-    // The table behind this rule: profiles/r02/nd_grid.txt (tools/two_in_flight.py --grid: windows 5..17, ranges
-    // 128 / 256 / 512, both costs at 1500 x 1000, either build alone and with two pairs in flight).
-    const int dcount = c.d_hi - c.d_lo + 1;
-    if (c.ww <= 9) return !c.ssd || dcount >= 448 ? kNDNarrow : kND; // two workgroups a CU: SAD -8..-15 % in flight;
-                                                                      // SSD -8 % from 512 on, +5 % alone at 320..384
-    if (c.ww <= 14) return c.ssd ? kNDNarrow : kND;                   // SSD -7..-17 % either way, SAD +15..+27 %
-    return c.ssd && dcount <= 224 ? kNDNarrow : kND;                  // 15..17 SSD: level at 1500 x 1000, -4 % (-24 % in
-                                                                      // flight, right view) at the reference's 900 x 750,
-                                                                      // D = 200; +6..+24 % from 256 on; SAD +8 % at 192
+    const int dcount = c.d_hi - c.d_lo + 1, out_w = c.ox1 - c.ox0, out_h = c.oy1 - c.oy0;
+    const int nch_total = ceil_div(dcount, sh.nd), passes = ceil_div(nch_total, max_chunks(sh));
+    int nch = ceil_div(nch_total, passes);
+    if (nch < min_chunks(sh)) nch = min_chunks(sh);
+    int nxr = kMaxT / nch;
+    const int need = ceil_div(out_w, sh.x);
+    if (nxr > need) nxr = need;
+    if (nxr < kMinXRuns) nxr = kMinXRuns;
+    const int tiles = ceil_div(out_w, nxr * sh.x);
+    double best = 0.0;
+    for (int sc = 1; sc <= out_h; ++sc) {
+        const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
+        if (st != sc) continue;
+        const double cost = ceil_div(tiles * st, 256) * (rows + 0.5 * (c.wh - 1) + 3.0);
+        if (sc == 1 || cost < best) best = cost;
+    }
+    return best * passes * (same_shape(sh, kShapeNarrow) ? 0.62 : 1.0);
 }
+
+// Columns x disparities per thread for this search: a function of the canonical problem alone (not of the device), so
+// that everything that reads the marching kernel's planes afterwards (smoothFactor, sub-pixel refine) derives the same
+// key layout.  Round 2 chose from a hand-made table of thresholds taken at one image size.  Now: whichever
+// instantiation the planner's own cost model gives fewer row times.  The 8 x 8 kernel does a hypothesis with ~20 %
+// fewer instructions than the 8 x 4 one (shorter target-image runs per hypothesis) and wins wherever both fill the chip
+// alike; 8 x 4 makes tiles half as wide for the same disparity range, which pays when the range is narrow (D <= ~128 at
+// 1500 columns: the 8 x 8 tiles are then so wide that strips get short and the window's warm-up rows dear) or the image
+// small.  Checked against profiles/r03/nd_grid.txt (1500 x 1000, windows 5 .. 17,
+// D = 128 / 256 / 512, both costs, either instantiation forced) and at 900 x 750 and 2964 x 1988
+// (profiles/r03/nd_rule_check.txt).
+static MarchShape march_shape(const Canon &c)
+{
+    static const MarchShape forced = [] {
+        const char *e = getenv("WS_MARCH_ND"); // development knob: 8 or 4
+        MarchShape f{0, 0};
+        if (e && atoi(e) == kND) f = kShapeWide;
+        else if (e && atoi(e) == kNDNarrow) f = kShapeNarrow;
+        return f;
+    }();
+    if (forced.x) return forced;
+    if (kND == kNDNarrow) return kShapeWide;
+    if (c.ox1 <= c.ox0 || c.oy1 <= c.oy0 || c.d_hi < c.d_lo) return kShapeWide;
+    return march_model_cost(c, kShapeNarrow) < march_model_cost(c, kShapeWide) ? kShapeNarrow : kShapeWide;
+}
+static int march_nd(const Canon &c) { return march_shape(c).nd; }
 
 static const MarchEntry *find_march(const Canon &c)
 {
-    const int nd = march_nd(c);
+    const MarchShape sh = march_shape(c);
     int n = (int)(sizeof kMarchWide / sizeof kMarchWide[0]);
     const MarchEntry *t = kMarchWide;
-    if (nd != kND) t = march_table_narrow(&n);
+    if (same_shape(sh, kShapeNarrow)) t = march_table_narrow(&n);
     for (int i = 0; i < n; ++i)
-        if (t[i].ww == c.ww && t[i].wh == c.wh && t[i].ssd == c.ssd && t[i].nd == nd) return &t[i];
+        if (t[i].x == sh.x && t[i].ww == c.ww && t[i].wh == c.wh && t[i].ssd == c.ssd && t[i].nd == sh.nd) return &t[i];
     return nullptr;
 }
 
@@ -110,6 +151,7 @@ bool march_supported(const Canon &c)
     if (dcount < 1) return false;
     // keys must stay inside (-2^28, 2^28)
     //   SSD: (2 * cross sum) << log2(ND)        SAD: window sum << tag bits
+    if (!c.ssd && march_pk_window(c.ww, c.wh)) return dcount <= 65536; // packed SAD: 16-bit cost, 16-bit global tie tag
     const long long worst = c.ssd ? 2LL * c.ww * c.wh * 3 * (march_centred(c) ? 128 * 128 : 255 * 255) * march_nd(c)
                                   : ((long long)c.ww * c.wh * 3 * 255) << tag_bits_for(c);
     return worst < (long long)kValidKeyBound;
@@ -123,7 +165,8 @@ static int march_slots_per_cu(const Canon &c, int nd, int threads)
     }();
     if (forced > 0) return forced;
     const MarchEntry *e = find_march(c);
-    const int guess = nd <= kNDNarrow && threads <= 512 && c.ww <= 9 ? 2 : 1;
+    // (without a device: the 8 x 4 kernels of packed SAD up to 6 x 6 and of SSD up to 3 x 3 stay within 128 VGPRs)
+    const int guess = same_shape(march_shape(c), kShapeNarrow) && threads <= 512 && (c.ssd ? c.ww <= 3 : c.ww <= 6) ? 2 : 1;
     if (!e) return guess;
     // one question per kernel and block size, asked once (LDS never is the limit at these sizes)
     static std::mutex mu;
@@ -147,8 +190,9 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
 {
     if (!march_supported(c)) return false;
     MarchLaunch m{};
-    const int nd = march_nd(c);
-    m.x_per_thread = kX;
+    const MarchShape sh = march_shape(c);
+    const int nd = sh.nd, X = sh.x;
+    m.x_per_thread = X;
     m.nd_per_thread = nd;
     m.max_threads = kMaxT;
     const int dcount = c.d_hi - c.d_lo + 1;
@@ -157,25 +201,25 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     // leave too few columns per tile); beyond that the range is cut into equal d-group passes that
     // meet in a plane of keys.
     const int nch_total = ceil_div(dcount, nd);
-    static const int max_chunks = [] {
+    static const int forced_chunks = [] {
         const char *e = getenv("WS_MAX_CHUNKS"); // development knob
         const int v = e ? atoi(e) : 0;
-        return v >= 8 && v <= kMaxT / kMinXRuns ? v : kMaxChunks;
+        return v >= 8 && v <= kMaxT / kMinXRuns ? v : 0;
     }();
-    m.passes = ceil_div(nch_total, max_chunks);
+    m.passes = ceil_div(nch_total, forced_chunks ? forced_chunks : max_chunks(sh));
     m.nch = ceil_div(nch_total, m.passes);
-    if (m.nch < 8) m.nch = 8;
+    if (m.nch < min_chunks(sh)) m.nch = min_chunks(sh);
     int maxt = kMaxT;
     if (tune_threads >= 64 && tune_threads < kMaxT) maxt = tune_threads / 64 * 64;
     int nxr = maxt / m.nch;
     if (tune_nxr > 0 && tune_nxr < nxr) nxr = tune_nxr;
-    const int need = ceil_div(out_w, kX); // no point in tiles wider than the image
+    const int need = ceil_div(out_w, X); // no point in tiles wider than the image
     if (nxr > need) nxr = need;
     if (nxr < kMinXRuns) nxr = kMinXRuns;
     if (nxr * m.nch > kMaxT) return false;
     m.nxr = nxr;
     m.threads = round_up(nxr * m.nch, 64);
-    const int tx = nxr * kX;
+    const int tx = nxr * X;
     m.tiles = ceil_div(out_w, tx);
     int strips;
     if (tune_strip_rows > 0) {
@@ -203,7 +247,7 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     m.strip_rows = ceil_div(out_h, strips);
     m.strips = ceil_div(out_h, m.strip_rows);
     const int dt = m.nch * nd;
-    const int nreg = kX / 4, nregb = march_nreg_b(kX, nd);
+    const int nreg = X / 4, nregb = march_nreg_b(X, nd);
     const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
               b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
               bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);

@@ -212,6 +212,97 @@ __device__ __forceinline__ void march_fused_ssd(int32_t (&V)[X][ND], int32_t (&b
     }
 }
 
+// ---- SAD in packed 16-bit halves (windows up to 9 x 9) -----------------------------------------------------------
+// A window sum of absolute differences is at most ww * wh * 3 * 255: up to 9 x 9 it fits 16 bits, and then two
+// disparities share every register and every instruction behind the pixel differences themselves:
+//   * the prefix chain of disparity d runs in the low half (v_sad_u8), the chain of d + 1 in the high half of the
+//     same accumulator (v_sad_hi_u8: D = (sum |a - b| << 16) + acc); a chain's total stays below 2^16, so the low
+//     half never carries into the high one;
+//   * entering minus leaving row, the window's difference of two prefix values and the accumulation into the running
+//     sums are one v_pk_sub_u16 / v_pk_add_u16 each per PAIR of disparities (modulo 2^16 per half: the running sum
+//     itself is exact because it fits);
+//   * only the running minimum needs (cost, tie tag) keys: (V << 16) | tag for the low half is one v_lshl_or_b32,
+//     (V & 0xffff0000) | tag for the high half one v_and_or_b32, the minimum of both and the best so far one
+//     v_min3_u32.  A tag register with its upper half set poisons a disparity beyond d_hi for free; candidates whose
+//     target centre leaves [b_lo, b_hi] get their cost field forced to 0xffff by one more v_or -- only in the
+//     workgroups that have such candidates at all (the tiles near the image's edge: a uniform branch around the loops).
+// Per hypothesis in the steady state (X = 8, 9 x 9): 4.0 (chains) + 1.0 + 0.5 + 0.5 (packed T, difference, accumulate)
+// + 1.5 (keys, min) = 7.5 instructions, against 8.5 for the 32-bit form; half the running-sum registers.
+__host__ __device__ constexpr bool march_pk_window(int ww, int wh) { return ww * wh * 3 * 255 <= 65535; }
+constexpr uint32_t kPkNone = 0xffff0000u; // cost field of "no valid candidate" (a valid cost is at most 61 965)
+
+typedef unsigned short ws_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (ws_u16x2)(__builtin_bit_cast(ws_u16x2, a) - __builtin_bit_cast(ws_u16x2, b))); // v_pk_sub_u16
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (ws_u16x2)(__builtin_bit_cast(ws_u16x2, a) + __builtin_bit_cast(ws_u16x2, b))); // v_pk_add_u16
+}
+
+// PHASE 0: a row enters, no keys.  1: a row enters, keys.  2: a row enters, a row leaves (qa / qb), keys.
+template <int X, int ND, int WW, int PHASE, bool MASKED>
+__device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&best)[X], const uint32_t (&pa)[X + WW - 1],
+                                         const uint32_t (&pb)[X + WW + ND - 2], const uint32_t (&qa)[X + WW - 1],
+                                         const uint32_t (&qb)[X + WW + ND - 2], const uint32_t (&tagr)[ND],
+                                         const uint32_t (&mk)[X + ND - 1])
+{
+    constexpr int NA = X + WW - 1;
+    auto finish = [&](const uint32_t (&T)[NA], int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            const uint32_t w = x ? pk_sub(T[x + WW - 1], T[x - 1]) : T[WW - 1];
+            const uint32_t v = pk_add(Vp[x][j / 2], w);
+            Vp[x][j / 2] = v;
+            if constexpr (PHASE >= 1) {
+                uint32_t k0 = (v << 16) | tagr[j];              // disparity j      (v_lshl_or_b32)
+                uint32_t k1 = (v & 0xffff0000u) | tagr[j + 1];  // disparity j + 1  (v_and_or_b32)
+                if constexpr (MASKED) {
+                    k0 |= mk[x - j + ND - 1];
+                    k1 |= mk[x - j + ND - 2];
+                }
+                best[x] = min(best[x], min(k0, k1));            // v_min3_u32
+            }
+        }
+    };
+    if constexpr (PHASE == 2) {
+        // the entering and the leaving row's chains of one disparity pair interleave in the issue stream
+#pragma unroll
+        for (int j = 0; j < ND; j += 2) {
+            uint32_t T[NA];
+            uint32_t sn = 0, so = 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                sn = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 1], sn);
+                so = __builtin_amdgcn_sad_u8(qa[i], qb[i - j + ND - 1], so);
+                sn = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 2], sn);
+                so = __builtin_amdgcn_sad_hi_u8(qa[i], qb[i - j + ND - 2], so);
+                T[i] = pk_sub(sn, so);
+            }
+            finish(T, j);
+        }
+    } else {
+        // one row only: the chains of two disparity pairs interleave
+#pragma unroll
+        for (int j = 0; j < ND; j += 4) {
+            uint32_t T0[NA], T1[NA];
+            uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                s0 = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 1], s0);
+                s1 = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 3], s1);
+                s0 = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 2], s0);
+                s1 = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 4], s1);
+                T0[i] = s0;
+                T1[i] = s1;
+            }
+            finish(T0, j);
+            finish(T1, j + 2);
+        }
+    }
+}
+
 template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
@@ -222,8 +313,10 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
     // merge slots: SSD (cost << LT | 7) : global tie tag as one signed 64-bit key, SAD the 32-bit key itself;
     // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
-    typedef typename std::conditional<SSD, long long, int32_t>::type slot_t;
-    const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : (slot_t)INT_MAX;
+    // (packed SAD: (cost << 16) | global tie tag as an UNSIGNED 32-bit key, cost field 0xffff = no valid candidate)
+    constexpr bool PK = !SSD && march_pk_window(WW, WH);
+    typedef typename std::conditional<SSD, long long, typename std::conditional<PK, uint32_t, int32_t>::type>::type slot_t;
+    const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : PK ? (slot_t)0xffffffffu : (slot_t)INT_MAX;
 
     extern __shared__ uint4 ws_smem4[];
     uint32_t *smem = reinterpret_cast<uint32_t *>(ws_smem4);
@@ -271,23 +364,43 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     // the chunk's distance from the preferred end of the padded range [d_lo, d_top]
     const int ctag = g.prefer_large ? g.d_top - d0 - (ND - 1) : d0 - g.d_lo;
 
-    int32_t V[X][ND];
+    int32_t V[PK ? 1 : X][PK ? 1 : ND];
+    uint32_t Vp[PK ? X : 1][PK ? ND / 2 : 1], tagr[PK ? ND : 1], mk[PK ? X + ND - 1 : 1];
+    bool masked = false; // packed SAD: does this tile hold candidates whose target centre is out of range? (uniform)
+    if constexpr (PK) {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
-        const int d = d0 + j;
-        if constexpr (SSD) {
-            // local tag: the preferred disparity of a tie gets the smaller tag
-            const int tag = g.prefer_large ? (ND - 1 - j) : j;
-            const int32_t init = (d <= g.d_hi) ? tag : (kPoison + tag);
+        for (int x = 0; x < X; ++x)
 #pragma unroll
-            for (int x = 0; x < X; ++x) V[x][j] = init;
-        } else {
-            // global tag; both validity rules (d range, target centre range) fold into V
-            const int tag = g.prefer_large ? g.d_hi - d : d - g.d_lo;
+            for (int j = 0; j < ND / 2; ++j) Vp[x][j] = 0u;
 #pragma unroll
-            for (int x = 0; x < X; ++x) {
-                const int xb = tile_x0 + r * X + x - d + g.boff;
-                V[x][j] = (d <= g.d_hi && xb >= g.b_lo && xb <= g.b_hi) ? tag : kPoison;
+        for (int j = 0; j < ND; ++j) { // global tag; a disparity beyond d_hi is poisoned through its tag register
+            const int d = d0 + j;
+            tagr[j] = (uint32_t)(g.prefer_large ? g.d_hi - d : d - g.d_lo) & 0xffffu;
+            if (d > g.d_hi) tagr[j] |= kPkNone;
+        }
+        // target centre of (x, j): tile_x0 + r X + x - (d0 + j) + boff, i.e. xb0 + m with m = x - j + ND - 1
+        const int xb0 = tile_x0 + r * X - d0 + g.boff - (ND - 1);
+#pragma unroll
+        for (int m = 0; m < X + ND - 1; ++m) mk[m] = (xb0 + m >= g.b_lo && xb0 + m <= g.b_hi) ? 0u : kPkNone;
+        masked = tile_x0 - dhi_t + g.boff < g.b_lo || tile_x0 + tx - 1 - g.d_first + g.boff > g.b_hi;
+    } else {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int d = d0 + j;
+            if constexpr (SSD) {
+                // local tag: the preferred disparity of a tie gets the smaller tag
+                const int tag = g.prefer_large ? (ND - 1 - j) : j;
+                const int32_t init = (d <= g.d_hi) ? tag : (kPoison + tag);
+#pragma unroll
+                for (int x = 0; x < X; ++x) V[x][j] = init;
+            } else {
+                // global tag; both validity rules (d range, target centre range) fold into V
+                const int tag = g.prefer_large ? g.d_hi - d : d - g.d_lo;
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    const int xb = tile_x0 + r * X + x - d + g.boff;
+                    V[x][j] = (d <= g.d_hi && xb >= g.b_lo && xb <= g.b_hi) ? tag : kPoison;
+                }
             }
         }
     }
@@ -330,11 +443,13 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             if (x < g.ox1 && (g.pass_mode == 0 || g.pass_mode == 3)) {
                 const int xo = g.mirror ? g.wa - 1 - x : x;
                 float val;
-                const bool none = SSD ? (int32_t)((long long)key >> 32) >= kValidKeyBound : (int32_t)key >= kValidKeyBound;
+                const bool none = SSD  ? (int32_t)((long long)key >> 32) >= kValidKeyBound
+                                  : PK ? (uint32_t)key >= kPkNone
+                                       : (int32_t)key >= kValidKeyBound;
                 if (none) {
                     val = g.fallback_neg ? -(float)xo : (float)xo;
                 } else {
-                    const int gtag = SSD ? (int)(uint32_t)key : ((int)key & ((1 << g.tag_bits) - 1));
+                    const int gtag = SSD ? (int)(uint32_t)key : PK ? (int)((uint32_t)key & 0xffffu) : ((int)key & ((1 << g.tag_bits) - 1));
                     val = (float)(g.prefer_large ? (SSD ? g.d_top : g.d_hi) - gtag : g.d_lo + gtag);
                 }
                 // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
@@ -344,6 +459,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
                     int32_t cst;
                     if constexpr (SSD) cst = (int32_t)((long long)key >> 32) >> LT;
+                    else if constexpr (PK) cst = (int32_t)((uint32_t)key >> 16);
                     else cst = (int32_t)key >> g.tag_bits;
                     g.cost_out[(size_t)y * g.cost_pitch + xo] = cst;
                 }
@@ -355,8 +471,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     // strip's first output row (nothing leaves yet), 2: steady state (a row enters, a row leaves, a row comes out).
     // Each phase is a loop of its own: with one loop and branches on the step number the compiler joined the three
     // variants' running sums at the bottom of the body -- 64 v_mov per thread and step (13 % of the instructions).
-    auto step = [&](int a, auto phase) __attribute__((always_inline)) {
+    auto step = [&](int a, auto phase, auto mflag) __attribute__((always_inline)) {
         constexpr int PHASE = decltype(phase)::value;
+        constexpr bool MASKED = decltype(mflag)::value;
         const int oi = a - (WH - 1); // output row index inside the strip produced by this step
         if constexpr (PHASE == 2) flush(oi);
 
@@ -373,40 +490,61 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
         // 3. arithmetic
         if (worker) {
-            int32_t best[X];
-#pragma unroll
-            for (int x = 0; x < X; ++x) best[x] = INT_MAX;
             const uint32_t *addA = ringA + add_slot * a_w + ia, *addB = ringB + add_slot * b_w + ib;
             const uint32_t *subA = ringA + sub_slot * a_w + ia, *subB = ringB + sub_slot * b_w + ib;
-            const int32_t *brow = biasr + (oi & 1) * bi_w + ib;
-            if constexpr (PHASE == 0) {
-                march_row<X, ND, WW, SSD, CENTRED, +1, false>(V, best, addA, ro_a, addB, ro_b, nullptr, 0, shift);
-            } else if constexpr (PHASE == 1) {
-                march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
-            } else if constexpr (SSD && kFuseSsd) { // row a enters and row a - WH leaves in one chain
-                uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2], bi[X + ND - 1];
-                march_load<X, ND, WW, true, true>(pa, pb, bi, addA, ro_a, addB, ro_b, brow, ro_bi);
-                lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
-                lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
+            slot_t *sl = slots + (oi & 1) * tx + r;
+            if constexpr (PK) {
+                uint32_t bestp[X];
 #pragma unroll
-                for (int i = 0; i < X + WW - 1; ++i) qa[i] = ~qa[i];
-                march_fused_ssd<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
+                for (int x = 0; x < X; ++x) bestp[x] = 0xffffffffu;
+                uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2];
+                lds_run<X + WW - 1, NREG>(pa, addA, ro_a);
+                lds_run<X + WW + ND - 2, NREGB>(pb, addB, ro_b);
+                if constexpr (PHASE == 2) {
+                    lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
+                    lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
+                }
+                march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
+                if constexpr (PHASE >= 1) {
+#pragma unroll
+                    for (int x = 0; x < X; ++x) atomicMin(sl + x * g.nxr, bestp[x]); // ds_min_u32
+                }
             } else {
-                march_row<X, ND, WW, SSD, CENTRED, -1, false>(V, best, subA, ro_a, subB, ro_b, nullptr, 0, shift);
-                march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
-            }
-            if constexpr (PHASE >= 1) {
-                slot_t *sl = slots + (oi & 1) * tx + r;
+                int32_t best[X];
 #pragma unroll
-                for (int x = 0; x < X; ++x) {
-                    const int32_t bk = best[x];
-                    // no validity test here: a poisoned key is just a large one, the flush sorts it out
-                    if constexpr (SSD) {
-                        const uint32_t gtag = (uint32_t)(bk & (ND - 1)) | (uint32_t)ctag; // v_and_or_b32
-                        const long long key = (long long)(((unsigned long long)(uint32_t)(bk | (ND - 1)) << 32) | gtag);
-                        atomicMin(sl + x * g.nxr, key); // ds_min_i64, lanes on consecutive slots
-                    } else {
-                        atomicMin(sl + x * g.nxr, bk); // ds_min_i32
+                for (int x = 0; x < X; ++x) best[x] = INT_MAX;
+                const int32_t *brow = biasr + (oi & 1) * bi_w + ib;
+                if constexpr (PHASE == 0) {
+                    march_row<X, ND, WW, SSD, CENTRED, +1, false>(V, best, addA, ro_a, addB, ro_b, nullptr, 0, shift);
+                } else if constexpr (PHASE == 1) {
+                    march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
+                } else if constexpr (SSD && kFuseSsd) { // row a enters and row a - WH leaves in one chain
+                    uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2], bi[X + ND - 1];
+                    march_load<X, ND, WW, true, true>(pa, pb, bi, addA, ro_a, addB, ro_b, brow, ro_bi);
+                    lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
+                    lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
+#pragma unroll
+                    for (int i = 0; i < X + WW - 1; ++i) qa[i] = ~qa[i];
+                    march_fused_ssd<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
+                } else {
+                    march_row<X, ND, WW, SSD, CENTRED, -1, false>(V, best, subA, ro_a, subB, ro_b, nullptr, 0, shift);
+                    // (nothing of the entering row moves up into the leaving row's arithmetic: both rows' pixels at once
+                    // cost the wide windows up to 26 spilled registers)
+                    __builtin_amdgcn_sched_barrier(0);
+                    march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
+                }
+                if constexpr (PHASE >= 1) {
+#pragma unroll
+                    for (int x = 0; x < X; ++x) {
+                        const int32_t bk = best[x];
+                        // no validity test here: a poisoned key is just a large one, the flush sorts it out
+                        if constexpr (SSD) {
+                            const uint32_t gtag = (uint32_t)(bk & (ND - 1)) | (uint32_t)ctag; // v_and_or_b32
+                            const long long key = (long long)(((unsigned long long)(uint32_t)(bk | (ND - 1)) << 32) | gtag);
+                            atomicMin(reinterpret_cast<long long *>(sl) + x * g.nxr, key); // ds_min_i64, lanes on consecutive slots
+                        } else {
+                            atomicMin(reinterpret_cast<int32_t *>(sl) + x * g.nxr, bk); // ds_min_i32
+                        }
                     }
                 }
             }
@@ -419,16 +557,21 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         if (++out_slot == NR) out_slot = 0;
     };
 
-    int a = 0; // (nsteps >= WH: a strip has at least one row)
-    for (; a < WH - 1; ++a) step(a, std::integral_constant<int, 0>());
-    step(a++, std::integral_constant<int, 1>());
-    for (; a < nsteps; ++a) step(a, std::integral_constant<int, 2>());
+    // (nsteps >= WH: a strip has at least one row)
+    auto run = [&](auto mflag) __attribute__((always_inline)) {
+        int a = 0;
+        for (; a < WH - 1; ++a) step(a, std::integral_constant<int, 0>(), mflag);
+        step(a++, std::integral_constant<int, 1>(), mflag);
+        for (; a < nsteps; ++a) step(a, std::integral_constant<int, 2>(), mflag);
+    };
+    if (PK && masked) run(std::true_type()); // (uniform per workgroup: every wave meets the same barriers either way)
+    else run(std::false_type());
     flush(nsteps - (WH - 1)); // the last row
 }
 
 typedef void (*MarchFn)(const MarchArgs);
 struct MarchEntry {
-    int ww, wh, ssd, nd;
+    int x, ww, wh, ssd, nd; // columns x disparities per thread, window, cost
     MarchFn fn;
     MarchFn fn_cost; // the same kernel also writing the winners' costs (right-view window sizes only)
     const char *name;
@@ -443,18 +586,18 @@ struct MarchEntry {
 #define WS_MAXT 512
 #endif
 constexpr int kX = WS_X, kND = WS_ND, kMaxT = WS_MAXT; // build-time tuning (tools/variants.py)
-constexpr int kNDNarrow = 4;                           // the second instantiation of every window (march_nd)
-// the flush hands one output column to one thread (k < tx <= NT): that needs nxr * X <= round_up(nxr * nch, 64), which
-// nch >= 8 gives for X <= 8 only
-static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns with one pass of the workgroup: X <= 8 (nch >= 8)");
+constexpr int kNDNarrow = 4;                           // the second instantiation of every window (march_shape)
+// the flush hands one output column to one thread (k < tx <= NT): that needs nxr * X <= round_up(nxr * nch, 64), i.e.
+// at least X d-chunks per tile (march_plan: nch >= max(8, X))
+static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns with one pass of the workgroup: nch >= X");
 
 #define WS_MARCH_ENTRY_ND(W, H, N, TAG)                                                                          \
-    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H TAG ">"}, \
-    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H TAG ">"}
+    {kX, W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, nullptr, "ws_march_kernel<sad," #W "x" #H TAG ">"}, \
+    {kX, W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, nullptr, "ws_march_kernel<ssd," #W "x" #H TAG ">"}
 #define WS_MARCH_ENTRY_COST_ND(W, H, N, TAG)                                                                   \
-    {W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, ws_march_kernel<kX, N, W, H, false, kMaxT, true>, \
-     "ws_march_kernel<sad," #W "x" #H TAG ">"},                                                                \
-    {W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, ws_march_kernel<kX, N, W, H, true, kMaxT, true>,   \
+    {kX, W, H, 0, N, ws_march_kernel<kX, N, W, H, false, kMaxT>, ws_march_kernel<kX, N, W, H, false, kMaxT, true>, \
+     "ws_march_kernel<sad," #W "x" #H TAG ">"},                                                                    \
+    {kX, W, H, 1, N, ws_march_kernel<kX, N, W, H, true, kMaxT>, ws_march_kernel<kX, N, W, H, true, kMaxT, true>,   \
      "ws_march_kernel<ssd," #W "x" #H TAG ">"}
 // every window: left view bs x bs, right view (bs-1) x (bs-1)
 #define WS_MARCH_TABLE(N, TAG)                                                                                         \
@@ -465,6 +608,10 @@ static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns wit
     WS_MARCH_ENTRY_COST_ND(10, 10, N, TAG), WS_MARCH_ENTRY_COST_ND(12, 12, N, TAG),                                    \
     WS_MARCH_ENTRY_COST_ND(14, 14, N, TAG), WS_MARCH_ENTRY_COST_ND(16, 16, N, TAG)
 
+// (Measured and dropped in round 3: packed SAD with 16 columns x 4 disparities per thread -- 6.25 instead of 7.75
+// instructions per hypothesis at 9 x 9, since the chains' start-up is spread over twice the columns, and 221 VGPRs --
+// took 1.11 ms instead of 0.885 at config 3: twice the LDS merges and 30 % more LDS reads per hypothesis cost more than
+// the instructions saved.  16 x 8 does not fit the register file: 145 spilled registers.)
 // the 4-disparities-per-thread instantiations (ws_march_nd4.hip)
 const MarchEntry *march_table_narrow(int *count);
 

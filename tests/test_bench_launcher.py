@@ -30,21 +30,25 @@ def test_self_launch_two_ranks_weak_scaling():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    # a batch of 16 config-2 pairs per rank and step (bench.PAIRS_PER_STEP), alternating over two contexts
-    assert out["config"]["pairs_per_step"] == 32 and out["config"]["in_flight_per_gpu"] == 2
-    assert [r["pairs"] for r in out["per_rank"]] == [16, 16]
-    assert [r["rank"] for r in out["per_rank"]] == [0, 1]
+    # a batch of 704 config-2 pairs per rank and step (bench.PAIRS_PER_STEP), alternating over two contexts
+    assert out["config"]["pairs_per_step"] == 1408 and out["config"]["in_flight_per_gpu"] == 2
+    assert [r["items"] for r in out["per_rank"]] == [704, 704]
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["wall_ms"] > 0 for r in out["per_rank"])
     assert out["value"] > 0 and "REHEARSAL" in out["data"]
 
 
-def test_self_launch_config4_more_ranks_than_pairs():
-    """16 ranks, 15 pairs: one rank owns nothing and still joins every barrier."""
+def test_self_launch_config4_row_bands_over_many_ranks():
+    """16 ranks, 15 pairs: the pairs are cut into row bands (sharding.band_items), every rank joins every barrier,
+    the bands' map rows add up to the 15 whole maps, every rank reports its own wall time."""
+    from stereo_reconstruction_amd.synthetic import TRAINING_H
     p = run_bench("--gpus", "16", "--steps", "2", "--warmup", "1", "--workload", "config4", timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json_line(p.stdout)
     assert out["n_gpus"] == 16 and out["scaling"] == "strong"
-    counts = sorted(r["pairs"] for r in out["per_rank"])
-    assert sum(counts) == 15 and counts[0] == 0 and counts[-1] == 1
+    assert sum(r["items"] for r in out["per_rank"]) > 15 and min(r["items"] for r in out["per_rank"]) >= 1
+    total = sum(w * h * 256 for _, w, h, _ in TRAINING_H) / 1e6
+    assert abs(sum(r["Mdisp_map"] for r in out["per_rank"]) - total) < 1.0
+    assert all(r["wall_ms"] > 0 for r in out["per_rank"])
 
 
 def test_a_failing_rank_fails_the_job():

@@ -187,17 +187,19 @@ def test_planner_choices_without_a_device(wslib):
     assert c2["strip_rows"] * c2["strips"] >= 994
     p = ws.make_params(ws.VIEW_LEFT, 9, 0, 512, 1.0, "sad")
     c3 = ws.plan(p, (1988, 2964, 3), (1988, 2964, 3))
-    cap = 512            # 4 disparities per thread, 9 x 9: two workgroups share a CU (march_slots_per_cu)
+    cap = 256            # 8 disparities per thread: one workgroup per CU at a time (march_slots_per_cu)
     rounds = -(-c3["tiles"] * c3["strips"] // cap)
     assert c3["strip_rows"] >= 64 and rounds * cap - c3["tiles"] * c3["strips"] < 64    # tall strips, full rounds
     p = ws.make_params(ws.VIEW_LEFT, 9, 0, 1024, 1.0, "ssd")
     c5 = ws.plan(p, (2160, 3840, 3), (2160, 3840, 3))                                   # D = 1024: several d-group passes
     assert c5["passes"] >= 2 and c5["passes"] * c5["d_chunks"] * c5["d_per_thread"] >= 1024
-    # wide disparity ranges and wide windows take 4 disparities per thread (two searches can then share a CU),
-    # a config-2-like pair 8 (ws_march.hip: march_nd)
-    assert c2["d_per_thread"] == 8 and c3["d_per_thread"] == 4 and c5["d_per_thread"] == 4
+    # the thread shape follows the planner's own cost model (ws_march.hip: march_shape): 8 disparities per thread
+    # wherever both shapes fill the chip alike, 4 where the range is narrow for the image or the image small
+    assert c2["d_per_thread"] == 8 and c3["d_per_thread"] == 8 and c5["d_per_thread"] == 8
     p = ws.make_params(ws.VIEW_LEFT, 17, 0, 200, 1.0, "ssd")
     assert ws.plan(p, (750, 900, 3), (750, 900, 3))["d_per_thread"] == 4
+    p = ws.make_params(ws.VIEW_LEFT, 5, 0, 64, 1.0, "sad")
+    assert ws.plan(p, (375, 450, 3), (375, 450, 3))["d_per_thread"] == 4               # config 1's shape
     for view in (ws.VIEW_LEFT, ws.VIEW_RIGHT):
         for cost in ("ssd", "sad"):
             p = ws.make_params(view, 7, 0, 3000, 1.0, cost)                              # 10 x the width

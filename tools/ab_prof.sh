@@ -4,7 +4,7 @@
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
 export WS_CALLS=200
-for lib in $R/stereo_reconstruction_amd/libws_stereo.so $R/gpurun_variants/*.so; do
+for lib in $R/stereo_reconstruction_amd/libws_stereo.so $(ls $R/gpurun_variants/*.so 2>/dev/null); do
   export WS_STEREO_LIB=$lib
   echo "== $(basename $lib)"
   $R/tools/call_prof.sh ${tag}_$(basename $lib .so) "$@" | grep -v "^$"

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$1; shift
 cases="$@"
 : > $out
-for lib in $R/stereo_reconstruction_amd/libws_stereo.so $R/gpurun_variants/*.so; do
+for lib in $R/stereo_reconstruction_amd/libws_stereo.so $(ls $R/gpurun_variants/*.so 2>/dev/null); do
   for nd in 8 4; do
     echo "== $(basename $lib) WS_MARCH_ND=$nd" >> $out
     WS_STEREO_LIB=$lib WS_MARCH_ND=$nd python $R/tools/two_in_flight.py $cases 2>&1 | grep -v amdgpu.ids >> $out

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $grp --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --pairs-per-step 8 --no-cpu-baseline --no-extras "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

@@ -7,9 +7,9 @@ O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 python3 $R/bench.py > $O/config2_bench.json 2> $O/config2_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -o run -- python3 $R/bench.py --workload config2 --steps 20 --no-cpu-baseline --no-extras > $O/c2.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2s -o run -- python3 $R/bench.py --workload config2 --steps 20 --in-flight 1 --no-cpu-baseline --no-extras > $O/c2s.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o run -- python3 $R/bench.py --workload config3 --steps 20 --no-cpu-baseline --no-extras > $O/c3.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -o run -- python3 $R/bench.py --workload config2 --steps 20 --pairs-per-step 16 --no-cpu-baseline --no-extras > $O/c2.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2s -o run -- python3 $R/bench.py --workload config2 --steps 20 --pairs-per-step 16 --in-flight 1 --no-cpu-baseline --no-extras > $O/c2s.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o run -- python3 $R/bench.py --workload config3 --steps 20 --pairs-per-step 4 --no-cpu-baseline --no-extras > $O/c3.log 2>&1 || exit 1
 cp $O/c2/run_kernel_stats.csv $O/config2_kernel_stats.csv
 grep '^{' $O/c2.log | tail -1 > $O/config2_bench_profiled.json
 cp $O/c2s/run_kernel_stats.csv $O/config2_inflight1_kernel_stats.csv
