@@ -166,7 +166,8 @@ static int march_slots_per_cu(const Canon &c, int nd, int threads)
     if (forced > 0) return forced;
     const MarchEntry *e = find_march(c);
     // (without a device: the 8 x 4 kernels of packed SAD up to 6 x 6 and of SSD up to 3 x 3 stay within 128 VGPRs)
-    const int guess = same_shape(march_shape(c), kShapeNarrow) && threads <= 512 && (c.ssd ? c.ww <= 3 : c.ww <= 6) ? 2 : 1;
+    // every instantiation runs two waves per SIMD at least: two workgroups of 256 threads share a CU
+    const int guess = threads <= 256 || (same_shape(march_shape(c), kShapeNarrow) && threads <= 512 && (c.ssd ? c.ww <= 3 : c.ww <= 6)) ? 2 : 1;
     if (!e) return guess;
     // one question per kernel and block size, asked once (LDS never is the limit at these sizes)
     static std::mutex mu;
@@ -185,8 +186,34 @@ static int march_slots_per_cu(const Canon &c, int nd, int threads)
     return slots;
 }
 
+static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads, MarchLaunch *out);
+
+// Workgroups of 512 threads (two waves per SIMD, one workgroup per CU) or of 256 (one wave per SIMD each, two
+// workgroups per CU with barriers of their own: while one waits for its slowest wave the other one's wave has the
+// SIMD).  Measured (profiles/r03/threads256.txt, sweep_tiles_config3.csv): 256 is 6 % faster alone and 11 % with two
+// searches in flight at config 3, 2 .. 9 % faster in flight everywhere else, but 4 .. 6 % slower alone when the whole
+// search is one round of workgroups (config 2: its narrower tiles copy 1.7 x the target-row bytes per column and
+// there is no second round to hide that behind).  So: 256 when the search is more than one and a half rounds of
+// 512-thread workgroups, else 512; a caller that keeps a queue of pairs in flight on two contexts may ask for 256 throughout
+// (ws_set_tuning, threads = 256).
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out)
+{
+    static const int env_threads = [] {
+        const char *e = getenv("WS_PLAN_THREADS"); // development knob
+        return e ? atoi(e) : 0;
+    }();
+    if (tune_threads <= 0 && env_threads >= 64) tune_threads = env_threads;
+    if (!march_plan_threads(c, num_cus, tune_nxr, tune_strip_rows, tune_threads, out)) return false;
+    if (tune_threads > 0 || tune_nxr > 0 || tune_strip_rows > 0) return true;
+    MarchLaunch half{};
+    if (out->threads == kMaxT && 2 * out->tiles * out->strips >= 3 * num_cus &&
+        march_plan_threads(c, num_cus, 0, 0, kMaxT / 2, &half) && half.passes == out->passes)
+        *out = half;
+    return true;
+}
+
+static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads, MarchLaunch *out)
 {
     if (!march_supported(c)) return false;
     MarchLaunch m{};
