@@ -16,6 +16,7 @@
 #include <fstream>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace wsamd;
@@ -132,7 +133,9 @@ struct HostSpan {
 };
 
 // Classify and register the buffers of one call.  Spans with p == nullptr or n == 0 stay kUnused.
-void spans_attach(HostSpan *sp, int count, std::string *note)
+// may_register: false for buffers that stay attached while the CALLER'S code runs (ws_enqueue_host ... ws_wait): those
+// are never registered, see ws_enqueue_host.
+void spans_attach(HostSpan *sp, int count, std::string *note, bool may_register = true)
 {
     const uintptr_t ps = host_page();
     struct Hull { uintptr_t lo, hi; };
@@ -172,11 +175,17 @@ void spans_attach(HostSpan *sp, int count, std::string *note)
         const char *why = "";
         uintptr_t own = 0;
         bool done = false;
-        for (OwnRange &r : g_own) // inside a live range of ours: shared
-            if (r.lo <= h.lo && h.hi <= r.hi) { ++r.refs; how = HostSpan::kOurs; own = r.lo; done = true; break; }
+        if (may_register)
+            for (OwnRange &r : g_own) // inside a live range of ours: shared
+                if (r.lo <= h.lo && h.hi <= r.hi) { ++r.refs; how = HostSpan::kOurs; own = r.lo; done = true; break; }
         if (!done)
             for (const OwnRange &r : g_own)
-                if (h.lo < r.hi && r.lo < h.hi) { why = "overlaps a live registration of this library in part"; done = true; break; }
+                if (h.lo < r.hi && r.lo < h.hi) {
+                    why = may_register ? "overlaps a live registration of this library in part"
+                                       : "overlaps a registration another call of this library holds right now";
+                    done = true;
+                    break;
+                }
         if (!done) {
             // what the runtime knows already is the caller's (or a framework's): never registered or released here
             bool first = true, all = true, any = false;
@@ -193,6 +202,8 @@ void spans_attach(HostSpan *sp, int count, std::string *note)
                 how = HostSpan::kCallerPinned;
             } else if (any) {
                 why = "the runtime knows a part of the range (registered or allocated by the caller)";
+            } else if (!may_register) {
+                why = "pageable memory in a batch: registrations do not outlive a call of this library";
             } else {
                 const hipError_t e = hipHostRegister(reinterpret_cast<void *>(h.lo), h.hi - h.lo, hipHostRegisterDefault);
                 if (e == hipSuccess) {
@@ -235,6 +246,26 @@ void spans_attach(HostSpan *sp, int count, std::string *note)
     }
 }
 
+// The stages' host copies: a few threads for big buffers (one core moves ~14 GB/s, PCIe 50: a 9 MB image pair would
+// spend longer in memcpy than on the bus).
+void stage_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t kPiece = (size_t)1 << 20;
+    const unsigned want = (unsigned)std::min<size_t>(4, n / kPiece);
+    if (want < 2) { memcpy(dst, src, n); return; }
+    const size_t per = ((n / want) + 4095) & ~(size_t)4095;
+    std::thread helpers[3];
+    unsigned started = 0;
+    for (unsigned t = 1; t < want; ++t) {
+        const size_t off = t * per, len = off < n ? std::min(per, n - off) : 0;
+        if (!len) break;
+        try { helpers[started] = std::thread([=] { memcpy(dst + off, src + off, len); }); ++started; }
+        catch (...) { memcpy(dst + off, src + off, len); }
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (unsigned t = 0; t < started; ++t) helpers[t].join();
+}
+
 hipError_t stage_for(HostSpan &sp)
 {
     if (!sp.stage) return hipErrorInvalidValue;
@@ -256,7 +287,7 @@ hipError_t span_upload(HostSpan &sp, size_t off, void *dev, size_t bytes, hipStr
     if (!sp.loaded) {
         const hipError_t e = stage_for(sp);
         if (e != hipSuccess) return e;
-        memcpy(sp.stage->p, sp.p, sp.n);
+        stage_copy(sp.stage->p, sp.p, sp.n);
         sp.loaded = true;
     }
     return hipMemcpyAsync(dev, sp.stage->p + off, bytes, hipMemcpyHostToDevice, s);
@@ -306,9 +337,14 @@ hipError_t span_download(HostSpan &sp, size_t off, size_t pitch, const void *dev
 // these spans is idle.  Returns false (and a note) if the runtime refused a release: a bug to be reported, not ignored.
 void span_scatter(HostSpan &sp) // (the copies into the stage are through: the caller of this has synchronised)
 {
-    for (const HostSpan::Seg &g : sp.down)
+    for (const HostSpan::Seg &g : sp.down) {
+        if (g.host_pitch == g.row_bytes || g.rows == 1) { // dense: one copy
+            stage_copy(sp.p + g.host_off, sp.stage->p + g.stage_off, g.row_bytes * g.rows);
+            continue;
+        }
         for (size_t r = 0; r < g.rows; ++r)
             memcpy(sp.p + g.host_off + r * g.host_pitch, sp.stage->p + g.stage_off + r * g.row_bytes, g.row_bytes);
+    }
     sp.down.clear();
 }
 
@@ -1153,16 +1189,21 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     }
     uint8_t *d_left = job.d_in, *d_right = job.d_in + off_r;
     hipStream_t cs = ctx->copy_stream;
-    // The caller's buffers for the life of the batch (HostSpan; ws_wait releases them): copies from / to pageable
-    // memory would block this thread until they are done, and the next pair's upload could not run beside this
-    // pair's search.
+    // The caller's buffers for the life of the batch (HostSpan; ws_wait releases them).  Pageable memory is NOT
+    // registered here: a batch's buffers stay attached while the caller's own code runs between the calls -- its
+    // allocator maps, trims and recycles memory around (and inside) the pages a registration pinned -- and one full
+    // run of the GPU tests in round 3 ended in "Memory access fault by GPU ... on address <host heap page>" inside
+    // ws_wait, in the one test that kept a dozen registrations of heap memory alive across Python allocations
+    // (gpurun_out/r3_gpu_tests_12.txt).  Registrations of this library therefore never outlive one of
+    // its calls: pageable buffers of a batch cross through the job slots' pinned stages (a host memcpy each way),
+    // buffers the caller pinned itself cross directly, as before.
     const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     HostSpan sp[3];
     if (lin_l) { sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &job.h_left; }
     if (lin_r) { sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &job.h_right; }
     sp[2].p = static_cast<uint8_t *>(out); sp[2].n = ((size_t)out_stride * (oh - 1) + ow) * esz; sp[2].stage = &job.h_out;
     std::string note;
-    spans_attach(sp, 3, &note);
+    spans_attach(sp, 3, &note, false);
     const size_t first = ctx->batch_spans.size();
     for (int i = 0; i < 3; ++i) ctx->batch_spans.push_back(sp[i]);
     HostSpan *bs = ctx->batch_spans.data() + first; // (valid until the next push_back: only used inside this call)

@@ -111,7 +111,20 @@ static MarchShape march_shape(const Canon &c)
     if (forced.x) return forced;
     if (kND == kNDNarrow) return kShapeWide;
     if (c.ox1 <= c.ox0 || c.oy1 <= c.oy0 || c.d_hi < c.d_lo) return kShapeWide;
-    return march_model_cost(c, kShapeNarrow) < march_model_cost(c, kShapeWide) ? kShapeNarrow : kShapeWide;
+    // (asked a dozen times per search -- by the planner, the launchers, everything that needs the key layout -- and the
+    // model walks every strip count: remembered per thread for the last few problems, or a 30 us search would spend
+    // 50 us of host time on it)
+    struct Memo { int key[9]; MarchShape shape; };
+    thread_local Memo memo[4] = {};
+    thread_local int next = 0;
+    const int key[9] = {c.ox1 - c.ox0, c.oy1 - c.oy0, c.d_hi - c.d_lo + 1, c.ww, c.wh, c.ssd, 1, 0, 0};
+    for (const Memo &m : memo)
+        if (!memcmp(m.key, key, sizeof key)) return m.shape;
+    const MarchShape sh = march_model_cost(c, kShapeNarrow) < march_model_cost(c, kShapeWide) ? kShapeNarrow : kShapeWide;
+    memcpy(memo[next].key, key, sizeof key);
+    memo[next].shape = sh;
+    next = (next + 1) & 3;
+    return sh;
 }
 static int march_nd(const Canon &c) { return march_shape(c).nd; }
 

@@ -262,7 +262,9 @@ __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&b
                     k0 |= mk[x - j + ND - 1];
                     k1 |= mk[x - j + ND - 2];
                 }
-                best[x] = min(best[x], min(k0, k1));            // v_min3_u32
+                // (spelled out: the compiler splits min(best, min(k0, k1)) into two v_min_u32 for a third of the columns)
+                if (j == 0) best[x] = min(k0, k1); // (the first pair of a step: nothing to compare with yet)
+                else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(best[x]) : "v"(best[x]), "v"(k0), "v"(k1));
             }
         }
     };
@@ -429,7 +431,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
         const int k = tid - (NT - round_up_dev(tx, 64));
         if (k >= 0 && k < tx) {
-            const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r]
+            const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r] (round 3: [r][x] -- a thread's slots as neighbours, one
+                                                    // address for all eight ds_min -- saved 14 instructions a step and lost more to
+                                                    // LDS bank conflicts: config 2 0.120 -> 0.125 ms)
             slot_t key = sl[si];
             sl[si] = kEmpty;
             const int x = tile_x0 + k;
