@@ -224,8 +224,8 @@ __device__ __forceinline__ void march_fused_ssd(int32_t (&V)[X][ND], int32_t (&b
 //   * only the running minimum needs (cost, tie tag) keys: (V << 16) | tag for the low half is one v_lshl_or_b32,
 //     (V & 0xffff0000) | tag for the high half one v_and_or_b32, the minimum of both and the best so far one
 //     v_min3_u32.  A tag register with its upper half set poisons a disparity beyond d_hi for free; candidates whose
-//     target centre leaves [b_lo, b_hi] get their cost field forced to 0xffff by one more v_or -- only in the
-//     workgroups that have such candidates at all (the tiles near the image's edge: a uniform branch around the loops).
+//     target centre leaves [b_lo, b_hi] get their cost field forced to 0xffff by one more v_or -- only in the waves
+//     that hold such candidates next to valid ones (tiles at the image's edge: a wave-uniform branch around the loops).
 // Per hypothesis in the steady state (X = 8, 9 x 9): 4.0 (chains) + 1.0 + 0.5 + 0.5 (packed T, difference, accumulate)
 // + 1.5 (keys, min) = 7.5 instructions, against 8.5 for the 32-bit form; half the running-sum registers.
 __host__ __device__ constexpr bool march_pk_window(int ww, int wh) { return ww * wh * 3 * 255 <= 65535; }
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
     int32_t V[PK ? 1 : X][PK ? 1 : ND];
     uint32_t Vp[PK ? X : 1][PK ? ND / 2 : 1], tagr[PK ? ND : 1], mk[PK ? X + ND - 1 : 1];
-    bool masked = false; // packed SAD: does this tile hold candidates whose target centre is out of range? (uniform)
+    bool masked = false; // packed SAD: does this WAVE hold candidates whose target centre is out of range next to valid ones?
     if constexpr (PK) {
 #pragma unroll
         for (int x = 0; x < X; ++x)
@@ -384,7 +384,18 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         const int xb0 = tile_x0 + r * X - d0 + g.boff - (ND - 1);
 #pragma unroll
         for (int m = 0; m < X + ND - 1; ++m) mk[m] = (xb0 + m >= g.b_lo && xb0 + m <= g.b_hi) ? 0u : kPkNone;
-        masked = tile_x0 - dhi_t + g.boff < g.b_lo || tile_x0 + tx - 1 - g.d_first + g.boff > g.b_hi;
+        // Per WAVE: a thread all of whose target centres are out of range poisons its tags instead (free), so only the
+        // waves that hold a thread with SOME centres out of range -- the few on the diagonal x - d = b_lo of a tile at
+        // the image's edge -- pay the extra v_or per key.  (Wave-uniform: different waves of a workgroup then run
+        // different copies of the loops, every copy with the same barriers.)
+        const int xb_min = xb0, xb_max = xb0 + X + ND - 2;
+        const bool none_ok = worker && (xb_max < g.b_lo || xb_min > g.b_hi);
+        const bool some_bad = worker && !none_ok && (xb_min < g.b_lo || xb_max > g.b_hi);
+        if (none_ok) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) tagr[j] |= kPkNone;
+        }
+        masked = __builtin_amdgcn_ballot_w64(some_bad) != 0;
     } else {
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
@@ -568,7 +579,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         step(a++, std::integral_constant<int, 1>(), mflag);
         for (; a < nsteps; ++a) step(a, std::integral_constant<int, 2>(), mflag);
     };
-    if (PK && masked) run(std::true_type()); // (uniform per workgroup: every wave meets the same barriers either way)
+    if (PK && masked) run(std::true_type()); // (uniform per wave: every wave meets the same barriers either way)
     else run(std::false_type());
     flush(nsteps - (WH - 1)); // the last row
 }
