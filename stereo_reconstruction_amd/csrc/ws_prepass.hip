@@ -83,8 +83,8 @@ constexpr int kBiasStage = kBiasRows + kBiasMaxWh - 1;
 
 struct BiasLds {
     uint32_t raw[kBiasStage][64];              // the rows' bytes as aligned dwords; then the horizontal sums of the squares
-    uint32_t sq[kBiasStage][64 + kBiasMaxWh];  // squares of the pixels (3 channels summed)
-    uint32_t cs[kBiasStage][64 + kBiasMaxWh];  // channel sums of the pixels (fused kernel)
+    uint32_t sq[kBiasStage][64 + kBiasMaxWh + 3];  // squares of the pixels (3 channels summed); rows 16-byte aligned
+    uint32_t cs[kBiasStage][64 + kBiasMaxWh + 3];  // channel sums of the pixels (fused kernel)
     uint32_t hb[kBiasStage][64];               // their horizontal sums over the window
 };
 
@@ -136,39 +136,70 @@ __device__ __forceinline__ void bias_strip(const BiasArgs &g, int bx, int strip,
             if (k < nrows) l.raw[k][tx] = ld[t];
         }
         __syncthreads();
-        // (2) squares and channel sums of the pixels
-#pragma unroll 4
-        for (int k = ty; k < nrows; k += 4) {
-            const int yy = y0 + g.wy0 + k;
-            const bool row_ok = yy >= 0 && yy < g.hb;
-            const uint32_t sh0 = row_ok ? (uint32_t)(reinterpret_cast<uintptr_t>(g.src + (size_t)yy * g.stride + 3 * (size_t)xs_lo) & 3) : 0u;
-            for (int cx = tx; cx < ncols; cx += 64) {
-                const int xc = xc0 + cx;
+        // (2) squares and channel sums of the pixels: the nrows x ncols items dealt flat over the 256 threads (by rows
+        // of 64 lanes the 17 halo columns cost a whole second pass with a quarter of its lanes at work)
+        {
+            const uint32_t items = (uint32_t)(nrows * ncols), magic = 0xffffffffu / (uint32_t)ncols + 1u;
+            const uint32_t base_lo = (uint32_t)reinterpret_cast<uintptr_t>(g.src) + 3u * (uint32_t)xs_lo;
+            for (uint32_t it = threadIdx.x; it < items; it += 256) {
+                const int k = (int)__umulhi(it, magic), cx = (int)it - k * ncols; // (exact: it < 2^16, ncols <= 80)
+                const int yy = y0 + g.wy0 + k, xc = xc0 + cx;
                 uint32_t v = 0, c = 0;
-                if (row_ok && xc >= ca && xc < cb) {
+                if (yy >= 0 && yy < g.hb && xc >= ca && xc < cb) {
+                    const uint32_t sh0 = (base_lo + (uint32_t)yy * (uint32_t)g.stride) & 3u;
                     const uint32_t off = sh0 + 3u * (uint32_t)(g.mirror ? cb - 1 - xc : xc - ca); // byte offset in raw[k]
                     const uint32_t lo = l.raw[k][off >> 2], hi = l.raw[k][(off >> 2) + 1];
                     const uint32_t px = (__builtin_amdgcn_alignbyte(hi, lo, off & 3u) & 0xffffffu) ^ g.xor_mask;
                     v = g.centred ? pix_dot<true>(px, px, 0u) : pix_dot<false>(px, px, 0u);
-                    c = g.centred ? pix_dot<true>(px, 0x00010101u, 0u) : pix_dot<false>(px, 0x00010101u, 0u);
+                    if (g.kmul) c = g.centred ? pix_dot<true>(px, 0x00010101u, 0u) : pix_dot<false>(px, 0x00010101u, 0u);
                 }
                 l.sq[k][cx] = v;
                 l.cs[k][cx] = c;
             }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = ty; k < nrows; k += 4) {
-            uint32_t acc = 0, bcc = 0;
-            if (g.ww == 7) {
+        // horizontal window sums.  The BASELINE windows (7, 9): a thread takes 4 consecutive columns of a row, reads their
+        // 4 + ww - 1 values as three 16-byte words and forms the 4 sums from a running prefix (3.5 adds per sum instead of
+        // ww, a ninth of the LDS reads); other widths: a thread per (row, column), ww reads each.
+        auto hsum8 = [&](auto wwc) __attribute__((always_inline)) {
+            constexpr int WWC = decltype(wwc)::value;
+            static_assert(4 + WWC - 1 <= 12, "three 16-byte reads");
+            // (one plane after the other, four columns a task: the kernel must stay within 48 VGPRs to share a SIMD with
+            // the marching kernel's two waves, which is where a queue of pairs hides this pre-pass)
+            auto one = [&](auto plane, int k, int x0) __attribute__((always_inline)) {
+                constexpr bool SQ = decltype(plane)::value; // (the arrays named directly: LDS addresses stay 32-bit)
+                uint32_t q[12];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) { acc += l.sq[k][tx + i]; bcc += l.cs[k][tx + i]; }
-            } else {
-#pragma unroll 8
-                for (int i = 0; i < g.ww; ++i) { acc += l.sq[k][tx + i]; bcc += l.cs[k][tx + i]; }
+                for (int m = 0; m < 3; ++m) {
+                    const uint4 a = SQ ? *reinterpret_cast<const uint4 *>(&l.sq[k][x0 + 4 * m]) : *reinterpret_cast<const uint4 *>(&l.cs[k][x0 + 4 * m]);
+                    q[4 * m] = a.x; q[4 * m + 1] = a.y; q[4 * m + 2] = a.z; q[4 * m + 3] = a.w;
+                }
+#pragma unroll
+                for (int m = 1; m < 4 + WWC - 1; ++m) q[m] += q[m - 1]; // running prefix in place
+                const uint4 o = make_uint4(q[WWC - 1], q[WWC] - q[0], q[WWC + 1] - q[1], q[WWC + 2] - q[2]);
+                if (SQ) *reinterpret_cast<uint4 *>(&l.raw[k][x0]) = o; // (= hs)
+                else *reinterpret_cast<uint4 *>(&l.hb[k][x0]) = o;
+            };
+            for (int task = threadIdx.x; task < nrows * 16; task += 256) {
+                const int k = task >> 4, x0 = (task & 15) * 4;
+                one(std::true_type(), k, x0);
+                __builtin_amdgcn_sched_barrier(0); // (not both planes' values in registers at once)
+                if (g.kmul) one(std::false_type(), k, x0);
             }
-            hs[k][tx] = acc;
-            l.hb[k][tx] = bcc;
+        };
+        if (g.ww == 7) {
+            hsum8(std::integral_constant<int, 7>());
+        } else if (g.ww == 9) {
+            hsum8(std::integral_constant<int, 9>());
+        } else {
+#pragma unroll 1
+            for (int k = ty; k < nrows; k += 4) {
+                uint32_t acc = 0, bcc = 0;
+#pragma unroll 2
+                for (int i = 0; i < g.ww; ++i) { acc += l.sq[k][tx + i]; bcc += l.cs[k][tx + i]; }
+                hs[k][tx] = acc;
+                l.hb[k][tx] = bcc;
+            }
         }
         __syncthreads();
         // (3) down the chunk
@@ -177,14 +208,16 @@ __device__ __forceinline__ void bias_strip(const BiasArgs &g, int bx, int strip,
         if (in_plane && ya < yb) {
             int32_t *dst = g.bias + (size_t)ya * g.pitch + col;
             uint32_t e = e0;
-            if (g.kmul)
+            if (g.kmul) {
+#pragma unroll 1
                 for (int k = 0; k < ya - y0; ++k) e += (uint32_t)g.kmul * l.hb[k][tx];
+            }
             uint32_t acc = 0;
             if (centre_ok) {
-#pragma unroll 8
+#pragma unroll 1
                 for (int k = 0; k < g.wh; ++k) acc += hs[ya - y0 + k][tx];
             }
-#pragma unroll 4
+#pragma unroll 1
             for (int y = ya; y < yb; ++y, dst += g.pitch) {
                 const int k = y - y0;
                 *dst = centre_ok ? (int32_t)((acc + e) << g.shift) : (int32_t)((uint32_t)kPoison + (e << g.shift));
@@ -192,8 +225,10 @@ __device__ __forceinline__ void bias_strip(const BiasArgs &g, int bx, int strip,
                 if (g.kmul) e += (uint32_t)g.kmul * l.hb[k][tx];
             }
         }
-        if (g.kmul)
+        if (g.kmul) {
+#pragma unroll 1
             for (int k = 0; k < y1 - y0; ++k) e0 += (uint32_t)g.kmul * l.hb[k][tx];
+        }
     }
 }
 
@@ -213,6 +248,9 @@ struct PrepareArgs {
     int n_generic;
 };
 
+// (Kept within 48 VGPRs -- loops of the bias role not unrolled, its sums four columns at a time: beside the marching
+// kernel's two waves of up to 232 registers a SIMD has 48 left, and that is where the pre-pass of the next pair of a
+// queue runs, under the current pair's search.  The round-3 strip walk first took 93 and the overlap was gone.)
 __global__ void __launch_bounds__(256) ws_prepare_kernel(const PrepareArgs g)
 {
     // static LDS bounds the occupancy of every role (37 KB: four workgroups a CU): the raw bytes ((64 + 16) * 3 +
