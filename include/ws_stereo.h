@@ -232,6 +232,13 @@ int ws_device_status(ws_context *ctx, void *stream);
  * rectification.cpp:66-88 never leaves the host); for tests and reports.
  */
 int ws_last_host_paths(const ws_context *ctx, int how[3]);
+/*
+ * Which kernels the last ws_remove_disparity_outliers call ran: 0 = the double-precision box filter, 1 = the 32-bit
+ * integer one (every value of the map an integer in [0, 255] and kernel_size <= 4000: what reconstruction.cpp:5-18 is
+ * fed by main.cpp:47-53, an 8-bit PNG blurred over 500 x 500), 2 = the integer one met another value, left the map
+ * alone, and the double one ran after it.  The results are identical; for tests and reports.
+ */
+int ws_last_outliers_path(const ws_context *ctx, int *path);
 
 /* ---- Middlebury plumbing around the path ------------------------------------------ */
 /*

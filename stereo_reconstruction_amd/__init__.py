@@ -40,7 +40,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
-           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands", "ws_last_host_paths", "ws_device_status",
+           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands", "ws_last_host_paths", "ws_last_outliers_path", "ws_device_status",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -141,6 +141,7 @@ def load_library(build_if_missing=False):
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_set_host_bands.argtypes = [vp, ci]
     lib.ws_last_host_paths.argtypes = [vp, P(ci)]
+    lib.ws_last_outliers_path.argtypes = [vp, P(ci)]
     lib.ws_device_status.argtypes = [vp, vp]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
     lib.ws_pfm_write.argtypes = [ctypes.c_char_p, vp, ci, ci, ci]
@@ -322,6 +323,12 @@ class WindowSearch:
         how = (ctypes.c_int * 3)()
         self._check(self._lib.ws_last_host_paths(self._h, how))
         return tuple(("gathered", "registered", "caller-pinned", "staged")[v] for v in how)
+
+    def last_outliers_path(self):
+        """Which box filter the last remove_disparity_outliers ran: 'double', 'integer', 'integer-then-double'."""
+        v = ctypes.c_int(0)
+        self._check(self._lib.ws_last_outliers_path(self._h, ctypes.byref(v)))
+        return ("double", "integer", "integer-then-double")[v.value]
 
     def set_host_bands(self, bands=-1):
         self._check(self._lib.ws_set_host_bands(self._h, bands))

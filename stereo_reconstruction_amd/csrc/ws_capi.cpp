@@ -393,6 +393,8 @@ struct ws_context {
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
     unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up)
+    DevBuf d_flag;                     // 256 bytes: word 0 = the integer box filter met a value it cannot carry
+    int last_outliers_path = 0;        // ws_last_outliers_path
     int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
     std::vector<HostSpan> batch_spans; // caller buffers of the pairs enqueued since the last ws_wait (released there)
     HostBuf h_left, h_right, h_out;    // ws_search_host: gathered rows of cut-out images (gather_rows), stages (HostSpan)
@@ -870,7 +872,7 @@ void ws_destroy(ws_context *ctx)
         (void)spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), nullptr);
         ctx->batch_spans.clear();
     }
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64, &ctx->d_flag})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->h_out, &ctx->h_aux[0], &ctx->h_aux[1], &ctx->jobs[0].h_left, &ctx->jobs[0].h_right,
@@ -1040,6 +1042,13 @@ int ws_last_host_paths(const ws_context *ctx, int how[3])
 {
     if (!ctx || !how) return WS_ERR_ARG;
     for (int i = 0; i < 3; ++i) how[i] = ctx->last_how[i];
+    return WS_OK;
+}
+
+int ws_last_outliers_path(const ws_context *ctx, int *path)
+{
+    if (!ctx || !path) return WS_ERR_ARG;
+    *path = ctx->last_outliers_path;
     return WS_OK;
 }
 
@@ -1334,20 +1343,43 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
     const size_t n = (size_t)width * height;
     int rc;
     if ((rc = ensure(ctx, ctx->d_out, n * 4)) != WS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->d_out64, n * 8)) != WS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->d_out64, std::max(n * 8, outliers_u32_scratch_bytes(width, height, ctx->num_cus)))) != WS_OK) return rc;
+    if (!ctx->d_flag.p) {
+        if ((rc = ensure(ctx, ctx->d_flag, 256)) != WS_OK) return rc;
+        WS_HIP(ctx, hipMemsetAsync(ctx->d_flag.p, 0, 256, s));
+    }
     float *dmap = static_cast<float *>(ctx->d_out.p);
     // the caller's map for the duration of the call (HostSpan, like ws_search_host: no pageable copies)
     HostSpan sp[1];
     sp[0].p = reinterpret_cast<uint8_t *>(map); sp[0].n = ((size_t)stride * (height - 1) + width) * 4; sp[0].stage = &ctx->h_out;
     std::string note;
     spans_attach(sp, 1, &note);
+    // 8-bit maps (the pipeline's PNG: integers in [0, 255]) take the 32-bit integer kernels; a map with any other value
+    // raises status word 1, is left as uploaded, and goes through the double kernels after the first synchronisation
+    const bool try_u32 = ctx->d_flag.p && outliers_u32_applies(width, height, kernel_size, ctx->num_cus);
     rc = [&]() -> int {
         WS_HIP(ctx, span_upload_rows(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
-        WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
+        if (try_u32)
+            WS_HIP(ctx, launch_outliers_u32(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<uint32_t *>(ctx->d_out64.p),
+                                            static_cast<uint32_t *>(ctx->d_flag.p), ctx->status_dev + 1, ctx->num_cus, s));
+        else
+            WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
         WS_HIP(ctx, span_download(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
         return WS_OK;
     }();
-    const hipError_t es = hipStreamSynchronize(s);
+    hipError_t es = hipStreamSynchronize(s);
+    ctx->last_outliers_path = try_u32 ? 1 : 0;
+    if (rc == WS_OK && es == hipSuccess && try_u32 && ctx->status_host[1]) {
+        ctx->status_host[1] = 0;
+        ctx->last_outliers_path = 2;
+        rc = [&]() -> int {
+            WS_HIP(ctx, hipMemsetAsync(ctx->d_flag.p, 0, 256, s));
+            WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
+            WS_HIP(ctx, span_download(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
+            return WS_OK;
+        }();
+        es = hipStreamSynchronize(s);
+    }
     const bool released = spans_finish(sp, 1, &note);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", hipGetErrorString(es));
     if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", note.c_str());

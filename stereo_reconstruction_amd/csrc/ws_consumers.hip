@@ -254,6 +254,277 @@ __global__ void __launch_bounds__(256) ws_outlier_direct_kernel(const double *__
     if (d > __fmul_rn(thr_front, blurred) || d < __fmul_rn(thr_back, blurred)) *p = blurred;
 }
 
+// ---- the same on 8-bit maps, in 32-bit integers ------------------------------------------------
+// The pipeline's map is an 8-bit PNG (main.cpp:47-53): every value an integer in [0, 255].  When the row pass
+// finds nothing else, all sums are integers below 2^32 (k <= 4000): the prefixes and their differences are taken
+// modulo 2^32 (exact, whatever the intermediate wraps), the double pipes stay idle, and blurred =
+// (float)((double)sum * scale) is the very expression of the double path on the very same sum.  The intermediate
+// is ONE 32-bit word per pixel, row sum (< 2^24) | value << 24: the column pass reads 4 bytes per pixel instead of
+// 8 + 4 and never loads the map.  A map with any other value raises `flag` (device) and `host_word` (mapped, for
+// the host): the column pass then leaves the map alone and the caller runs the double path on it.
+// The words are stored BAND-MAJOR, dst[band][y][BW columns] with BW = 1 << lb: what the column pass of a band
+// reads is one contiguous block of h * BW words.
+constexpr uint32_t kBoxSumMask = 0x00ffffffu;
+constexpr int kBoxMaxK = 4000; // 4000 * 255 < 2^24 and 4000 * 4000 * 255 < 2^32
+
+template <class F>
+__device__ __forceinline__ uint32_t ext_prefix_u32(F P, int n, uint32_t ut)
+{
+    const uint32_t T = 2u * (uint32_t)n - 2u;
+    const uint32_t q = ut < T ? 0u : ut / T;
+    const int r = (int)(ut - q * T);
+    const uint32_t g = r <= n ? P(r) : P(n) + P(n - 1) - P(2 * n - 1 - r);
+    if (q == 0) return g;
+    return q * (P(n) + P(n - 1) - P(1)) + g;
+}
+
+template <class F>
+__device__ __forceinline__ uint32_t ext_window_u32(F P, int n, int x0, int k)
+{
+    if (x0 >= 0 && x0 + k <= n) return P(x0 + k) - P(x0); // no reflection: all but the border pixels when k < n
+    if (n == 1) return (uint32_t)k * P(1);
+    if (x0 >= 0) return ext_prefix_u32(P, n, (uint32_t)x0 + (uint32_t)k) - ext_prefix_u32(P, n, (uint32_t)x0);
+    return (ext_prefix_u32(P, n, (uint32_t)(-x0) + 1u) - P(1)) + ext_prefix_u32(P, n, (uint32_t)(x0 + k));
+}
+
+// workgroup i of n -> the unit it works on, so that the workgroups of one XCD (i mod 8: the dispatcher deals
+// workgroups round-robin over the 8 XCDs) own CONSECUTIVE units and the two halves of a 128-byte line that two
+// neighbouring units touch meet in one L2
+__device__ __forceinline__ int xcd_unit(int i, int n)
+{
+    const int q = n >> 3, r = n & 7, xcd = i & 7, j = i >> 3;
+    return xcd * q + min(xcd, r) + j;
+}
+
+// inclusive scan over the 64 lanes of a wave, all lanes active: Hillis-Steele inside each row of 16 lanes (DPP
+// row_shr, out-of-row sources read as 0), then the row totals across the rows (DPP row_bcast:15 / row_bcast:31)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // lane 15 of rows 0, 2 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // lane 31 -> rows 2, 3
+    return x;
+}
+
+// Window sum of the REFLECT_101-extended line when the window is no longer than the line (k <= n: one reflection
+// at most, on one side), without a branch: the part inside the line, what reflects off the left end (elements
+// 1 .. -lo), what reflects off the right end (elements 2n-1-hi .. n-2).  P(r) = sum of the first r elements.
+template <class F>
+__device__ __forceinline__ uint32_t short_window_u32(F P, int n, int lo, int k, uint32_t p1, uint32_t pn1)
+{
+    const int hi = lo + k;
+    return (P(min(hi, n)) - P(max(lo, 0))) + (P(max(1 - lo, 1)) - p1) + (pn1 - P(n - 1 - max(hi - n, 0)));
+}
+
+constexpr int kRowPer = 16; // pixels per thread and pass of the row kernel
+
+template <int NT> // threads of the workgroup that owns one row
+__global__ void __launch_bounds__(NT) ws_box_rows_u32_kernel(const float *__restrict__ src, int sp, uint32_t *__restrict__ dst,
+                                                             int w, int h, int k, int lb, uint32_t *__restrict__ flag,
+                                                             unsigned int *__restrict__ host_word)
+{
+    constexpr int NW = NT / 64, NTOT = kRowPer * NW; // NTOT <= 64: one wave scans the wave totals
+    static_assert(NTOT <= 64, "one wave scans the totals");
+    extern __shared__ uint32_t box_lds_u[]; // P[0 .. w], then tot[NTOT + 1]
+    uint32_t *P = box_lds_u, *tot = box_lds_u + (w + 1);
+    const int y = xcd_unit(blockIdx.x, h), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *row = src + (size_t)y * sp;
+    bool odd = false; // a value the 8-bit path cannot carry
+    uint32_t carry = 0;
+    if (tid == 0) P[0] = 0u;
+    // the row's inclusive prefix into P: pixel i sits in thread i % NT, register i / NT -- the coalesced order of the
+    // loads is the order of the scan (wave scans in registers, the 16 * NW wave totals through LDS)
+    for (int i0 = 0; i0 < w; i0 += kRowPer * NT) { // one pass for rows up to 16 * NT pixels
+        float f[kRowPer];
+#pragma unroll
+        for (int j = 0; j < kRowPer; ++j) {
+            const int i = i0 + j * NT + tid;
+            f[j] = i < w ? row[i] : 0.0f;
+        }
+        uint32_t sc[kRowPer];
+#pragma unroll
+        for (int j = 0; j < kRowPer; ++j) {
+            const uint32_t u = (uint32_t)f[j]; // saturating: negative and NaN -> 0, which then fails the comparison
+            odd |= !((float)u == f[j]) || u > 255u;
+            sc[j] = wave_incl_scan_u32(u);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < kRowPer; ++j) tot[j * NW + wv] = sc[j];
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const uint32_t t = lane < NTOT ? tot[lane] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(t);
+            if (lane < NTOT) tot[lane] = incl - t;
+            if (lane == 63) tot[NTOT] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRowPer; ++j) {
+            const int i = i0 + j * NT + tid;
+            if (i < w) P[i + 1] = carry + tot[j * NW + wv] + sc[j];
+        }
+        carry += tot[NTOT];
+        __syncthreads();
+    }
+    if (__any(odd) && lane == 0) {
+        *flag = 1u;
+        *host_word = 1u;
+    }
+    const int a = k / 2, bw1 = (1 << lb) - 1;
+    auto Pf = [&](int r) { return P[r]; };
+    auto word_at = [&](int x) { return (((uint32_t)(x >> lb) * (uint32_t)h + (uint32_t)y) << lb) + (uint32_t)(x & bw1); };
+    if (k <= w) {
+        const uint32_t p1 = P[1], pn1 = P[w - 1];
+#pragma unroll 4
+        for (int x = tid; x < w; x += NT)
+            dst[word_at(x)] = short_window_u32(Pf, w, x - a, k, p1, pn1) | (P[x + 1] - P[x]) << 24;
+    } else {
+        for (int x = tid; x < w; x += NT) dst[word_at(x)] = ext_window_u32(Pf, w, x - a, k) | (P[x + 1] - P[x]) << 24;
+    }
+}
+
+constexpr int kColMaxPerU = 36; // rows per thread at most
+
+template <int BW, int NT>
+__global__ void __launch_bounds__(NT) ws_outlier_cols_u32_kernel(const uint32_t *__restrict__ rows, float *__restrict__ map,
+                                                                  int mp, int w, int h, int k, float thr_front, float thr_back,
+                                                                  const uint32_t *__restrict__ flag)
+{
+    if (*flag) return; // the row pass met a value the 8-bit path cannot carry: the map stays as it is
+    extern __shared__ uint32_t box_lds_u[]; // C[(h + 1)][BW], then tot[NT / 64][BW]
+    constexpr int NCH = NT / BW, NWV = NT / 64;
+    uint32_t *C = box_lds_u, *tot = box_lds_u + (size_t)(h + 1) * BW;
+    const int band = xcd_unit(blockIdx.x, gridDim.x);
+    const int c = threadIdx.x % BW, ch = threadIdx.x / BW;
+    const int x = band * BW + c;
+    const int L = (h + NCH - 1) / NCH;
+    const int ya = min(ch * L, h), yb = min(ya + L, h);
+    const bool live = x < w;
+    const int n = yb - ya; // this thread's rows: ya .. ya + n - 1
+    const uint32_t *col = rows + (size_t)band * h * BW + c;
+    const uint32_t *mine = col + (size_t)ya * BW;
+    uint32_t v[kColMaxPerU];
+    // everything this thread will read from memory, in flight at once.  No guards: rows past the thread's own are
+    // the next thread's or the next band's, past the last band lies the padding outliers_u32_scratch_bytes adds
+#pragma unroll
+    for (int i = 0; i < kColMaxPerU; ++i) v[i] = mine[i * BW];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kColMaxPerU; ++i) {
+        v[i] = i < n ? v[i] : 0u;
+        sum += v[i] & kBoxSumMask;
+    }
+    // exclusive scan of the chunk totals down the column (lane = chunk-in-wave * BW + c), then across the waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = BW; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane >= 64 - BW) tot[wv * BW + c] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) { // all the reads at once, the waves above this one selected afterwards
+        const uint32_t t = tot[i * BW + c];
+        run += i < wv ? t : 0u;
+    }
+    if (ch == 0) C[c] = 0u;
+    uint32_t *cmine = C + (ya + 1) * BW + c;
+#pragma unroll
+    for (int i = 0; i < kColMaxPerU; ++i) {
+        run += v[i] & kBoxSumMask;
+        if (i < n) cmine[i * BW] = run;
+    }
+    __syncthreads();
+    if (!live) return;
+    const double scale = 1.0 / ((double)k * (double)k);
+    const int a = k / 2;
+    auto Pc = [&](int r) { return C[r * BW + c]; };
+    float *mrow = map + (size_t)ya * mp + x; // walks down the column with the rows
+    auto settle = [&](uint32_t acc, uint32_t word) {
+        const float blurred = (float)((double)acc * scale);
+        const float d = (float)(word >> 24);
+        if (d > __fmul_rn(thr_front, blurred) || d < __fmul_rn(thr_back, blurred)) *mrow = blurred;
+        mrow += mp;
+    };
+    if (k <= h) {
+        const uint32_t p1 = Pc(1), pn1 = Pc(h - 1);
+#pragma unroll
+        for (int i = 0; i < kColMaxPerU; ++i) {
+            if (i < n) settle(short_window_u32(Pc, h, ya + i - a, k, p1, pn1), v[i]);
+            if (i % 9 == 8) __builtin_amdgcn_sched_barrier(0); // nine rows' LDS reads in flight at a time: registers
+        }
+    } else { // windows taller than the map (small maps): the periodic form, the words read again
+        for (int y = ya; y < yb; ++y) settle(ext_window_u32(Pc, h, y - a, k), col[(size_t)y * BW]);
+    }
+}
+
+// band width of the column pass: a workgroup of 1024 threads (one per CU: ~100 VGPRs) owns BW columns of all rows;
+// narrow bands make more workgroups than CUs (rounds), wide ones leave CUs idle.  Modelled cost per round: a fixed
+// latency plus the band's pixels (fitted on 3840x2160 / 1500x1000 / 900x750, profiles/r03/consumers.txt).
+static int outliers_u32_band(int w, int h, int num_cus)
+{
+    constexpr size_t kLdsBudget = 150 * 1024;
+    static const char *forced = getenv("WS_BOX_COLS"); // band width: developer knob
+    int best = 0;
+    double best_cost = 0.0;
+    for (int bw : {4, 8, 16}) {
+        if ((size_t)(h + 1 + 16) * bw * sizeof(uint32_t) > kLdsBudget || ceil_div(h, 1024 / bw) > kColMaxPerU) continue;
+        if (forced && atoi(forced) == bw) return bw;
+        const int rounds = ceil_div(ceil_div(w, bw), std::max(1, num_cus));
+        const double cost = rounds * (4.0 + 0.43e-3 * (double)h * bw);
+        if (!best || cost < best_cost) {
+            best = bw;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+size_t outliers_u32_scratch_bytes(int w, int h, int num_cus)
+{
+    const int bw = outliers_u32_band(w, h, num_cus);
+    // (+ the rows a thread of the column pass may read past the last band's end)
+    return bw ? ((size_t)ceil_div(w, bw) * h + kColMaxPerU) * bw * sizeof(uint32_t) : 0;
+}
+
+bool outliers_u32_applies(int w, int h, int k, int num_cus)
+{
+    return outliers_u32_band(w, h, num_cus) != 0 && (size_t)(w + 1 + 80) * sizeof(uint32_t) <= 64 * 1024 && k <= kBoxMaxK &&
+           (size_t)(w + 16) * h < (1u << 30);
+}
+
+hipError_t launch_outliers_u32(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, uint32_t *scratch,
+                               uint32_t *flag, unsigned int *host_word, int num_cus, hipStream_t s)
+{
+    const int bw = outliers_u32_band(w, h, num_cus);
+    if (!bw || !outliers_u32_applies(w, h, k, num_cus)) return hipErrorInvalidValue;
+    const int lb = bw == 16 ? 4 : bw == 8 ? 3 : 2;
+    // rows: one workgroup of 256 threads per row (several rows per workgroup with the next row fetched during the
+    // stores measured slower at every size: profiles/r03/consumers.txt)
+    const size_t row_lds = (size_t)(w + 1 + 80) * sizeof(uint32_t);
+    hipLaunchKernelGGL(ws_box_rows_u32_kernel<256>, dim3(h), dim3(256), row_lds, s, map, mp, scratch, w, h, k, lb, flag, host_word);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto launch = [&](auto kernel) -> hipError_t {
+        const size_t lds = (size_t)(h + 1 + 16) * bw * sizeof(uint32_t);
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, bw)), dim3(1024), lds, s, scratch, map, mp, w, h, k, thr_front, thr_back, flag);
+        return hipGetLastError();
+    };
+    if (bw == 16) return launch(ws_outlier_cols_u32_kernel<16, 1024>);
+    if (bw == 8) return launch(ws_outlier_cols_u32_kernel<8, 1024>);
+    return launch(ws_outlier_cols_u32_kernel<4, 1024>);
+}
+
 hipError_t launch_outliers(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, double *scratch,
                            hipStream_t s)
 {

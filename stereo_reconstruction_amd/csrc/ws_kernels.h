@@ -121,6 +121,13 @@ hipError_t launch_warp(const float *src, int sw, int sh, int sp, float *dst, int
 // removeDisparityOutliers (reconstruction.cpp:5-18); scratch = w*h doubles
 hipError_t launch_outliers(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, double *scratch,
                            hipStream_t s);
+// the same for 8-bit maps (what the pipeline feeds it: an 8-bit PNG), all sums in 32-bit integers.  A map with any
+// value that is not an integer in [0, 255] sets *flag (device word, zero on entry) and *host_word (mapped host word)
+// and is left untouched: the caller then runs launch_outliers.  scratch = outliers_u32_scratch_bytes(w, h) bytes.
+bool outliers_u32_applies(int w, int h, int k, int num_cus);
+size_t outliers_u32_scratch_bytes(int w, int h, int num_cus);
+hipError_t launch_outliers_u32(float *map, int mp, int w, int h, int k, float thr_front, float thr_back, uint32_t *scratch,
+                               uint32_t *flag, unsigned int *host_word, int num_cus, hipStream_t s);
 // convertDisparityToDepth + back-projection (reconstruction.cpp:30-43, :152-196); depth / pos+col may be null
 hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float focal, float baseline, const float k[9],
                                  const uint8_t *bgr, int bstride, float *depth, int zp, float *pos, uint8_t *col,
