@@ -111,6 +111,7 @@ typedef struct {
     int threads, tiles, strips, strip_rows, lds_bytes;
     int interior_x0, interior_x1, interior_y0, interior_y1; /* outputs the marching kernel writes */
     int passes;                     /* d-group passes (disparity ranges wider than one tile holds) */
+    int tile_cols;                  /* columns a tile hands out: x_runs*x_per_thread, one run less for the halo-exchange SAD kernels */
 } ws_plan_info;
 int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int num_cus,
             ws_plan_info *out);

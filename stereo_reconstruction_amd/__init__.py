@@ -73,7 +73,7 @@ class _PlanInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "marching", "x_per_thread", "d_per_thread", "x_runs", "d_chunks", "threads", "tiles",
         "strips", "strip_rows", "lds_bytes", "interior_x0", "interior_x1", "interior_y0",
-        "interior_y1", "passes")]
+        "interior_y1", "passes", "tile_cols")]
 
 
 _lib = None

@@ -930,6 +930,7 @@ int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int
         out->interior_x1 = c.mirror ? c.wa - c.ox0 : c.ox1;
         out->interior_y0 = c.oy0; out->interior_y1 = c.oy1;
         out->passes = m.passes;
+        out->tile_cols = m.tile_cols;
     }
     return WS_OK;
 }

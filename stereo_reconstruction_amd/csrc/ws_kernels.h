@@ -44,6 +44,8 @@ struct MarchLaunch {
     int passes;                      // d-group passes (1 unless the disparity range is very wide)
     int threads;                     // workgroup size
     int tiles, strips, strip_rows;
+    int halo;                        // packed SAD with the halo exchange (march_pk_halo): tiles advance by (nxr - 1) * X columns
+    int tile_cols;                   // output columns per tile
     size_t lds_bytes;
     int max_threads;                 // launch-bounds variant (1024 or 768)
 };

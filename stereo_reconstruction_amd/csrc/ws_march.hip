@@ -53,6 +53,8 @@ constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1
 // reads more of plane B per hypothesis but lets the workgroups of two searches -- two contexts taking a queue of
 // pairs alternately, INTEGRATION.md -- share a CU.  The table behind march_nd's rule: profiles/r03/nd_grid.txt.
 static const MarchEntry kMarchWide[] = {WS_MARCH_TABLE(kND, "")};
+static const MarchEntry kMarchHalo[] = {WS_MARCH_HALO_ENTRY(7, 7), WS_MARCH_HALO_ENTRY(9, 9), WS_MARCH_HALO_ENTRY_COST(6, 6),
+                                       WS_MARCH_HALO_ENTRY_COST(8, 8)};
 
 // The thread shapes a search can run with: X columns x ND disparities per thread.
 struct MarchShape { int x, nd; };
@@ -139,6 +141,19 @@ static const MarchEntry *find_march(const Canon &c)
     return nullptr;
 }
 
+// the halo-exchange twin of the packed SAD kernel for this window, if there is one (and the wide shape was chosen)
+static const MarchEntry *find_march_halo(const Canon &c)
+{
+    static const bool off = [] {
+        const char *e = getenv("WS_MARCH_HALO"); // development knob: 0 = never
+        return e && atoi(e) == 0;
+    }();
+    if (off || c.ssd || !same_shape(march_shape(c), kShapeWide)) return nullptr;
+    for (const MarchEntry &e : kMarchHalo)
+        if (e.ww == c.ww && e.wh == c.wh) return &e;
+    return nullptr;
+}
+
 static int tag_bits_for(const Canon &c)
 {
     int bits = 1;
@@ -170,14 +185,14 @@ bool march_supported(const Canon &c)
     return worst < (long long)kValidKeyBound;
 }
 
-static int march_slots_per_cu(const Canon &c, int nd, int threads)
+static int march_slots_per_cu(const Canon &c, int nd, int threads, bool halo)
 {
     static const int forced = [] {
         const char *e = getenv("WS_PLAN_SLOTS"); // development knob
         return e ? atoi(e) : 0;
     }();
     if (forced > 0) return forced;
-    const MarchEntry *e = find_march(c);
+    const MarchEntry *e = halo ? find_march_halo(c) : find_march(c);
     // (without a device: the 8 x 4 kernels of packed SAD up to 6 x 6 and of SSD up to 3 x 3 stay within 128 VGPRs)
     // every instantiation runs two waves per SIMD at least: two workgroups of 256 threads share a CU
     const int guess = threads <= 256 || (same_shape(march_shape(c), kShapeNarrow) && threads <= 512 && (c.ssd ? c.ww <= 3 : c.ww <= 6)) ? 2 : 1;
@@ -220,8 +235,12 @@ bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, 
     if (!march_plan_threads(c, num_cus, tune_nxr, tune_strip_rows, tune_threads, out)) return false;
     if (tune_threads > 0 || tune_nxr > 0 || tune_strip_rows > 0) return true;
     MarchLaunch half{};
-    if (out->threads == kMaxT && 2 * out->tiles * out->strips >= 3 * num_cus &&
-        march_plan_threads(c, num_cus, 0, 0, kMaxT / 2, &half) && half.passes == out->passes)
+    // (halo-exchange plans trade d-group passes for runs per tile: their passes run back to back and count as rounds,
+    // and the smaller workgroup has more of them by construction.  Config 3, 512 -> 256 threads: 3.94 -> 4.13 * 10^6
+    // Mdisp/s with two searches in flight, 3.85 -> 3.52 alone -- gpurun_out/r3_halo.txt)
+    const int launches = out->halo ? out->passes : 1;
+    if (out->threads == kMaxT && 2 * out->tiles * out->strips * launches >= 3 * num_cus &&
+        march_plan_threads(c, num_cus, 0, 0, kMaxT / 2, &half) && (half.passes == out->passes || (half.halo && out->halo)))
         *out = half;
     return true;
 }
@@ -246,25 +265,25 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         const int v = e ? atoi(e) : 0;
         return v >= 8 && v <= kMaxT / kMinXRuns ? v : 0;
     }();
+    int maxt = kMaxT;
+    if (tune_threads >= 64 && tune_threads < kMaxT) maxt = tune_threads / 64 * 64;
     m.passes = ceil_div(nch_total, forced_chunks ? forced_chunks : max_chunks(sh));
     m.nch = ceil_div(nch_total, m.passes);
     if (m.nch < min_chunks(sh)) m.nch = min_chunks(sh);
-    int maxt = kMaxT;
-    if (tune_threads >= 64 && tune_threads < kMaxT) maxt = tune_threads / 64 * 64;
     int nxr = maxt / m.nch;
     if (tune_nxr > 0 && tune_nxr < nxr) nxr = tune_nxr;
     const int need = ceil_div(out_w, X); // no point in tiles wider than the image
     if (nxr > need) nxr = need;
     if (nxr < kMinXRuns) nxr = kMinXRuns;
-    if (nxr * m.nch > kMaxT) return false;
-    m.nxr = nxr;
-    m.threads = round_up(nxr * m.nch, 64);
-    const int tx = nxr * X;
-    m.tiles = ceil_div(out_w, tx);
-    int strips;
-    if (tune_strip_rows > 0) {
-        strips = ceil_div(out_h, tune_strip_rows);
-    } else {
+    // the rest of a plan once (halo, passes, nch, nxr) are set: tiles, strips, LDS; returns its modelled cost in row
+    // steps of the plain kernel (0 = does not fit)
+    auto complete = [&](MarchLaunch &p, int runs) -> double {
+        if (runs * p.nch > kMaxT) return 0.0;
+        p.nxr = runs;
+        p.threads = round_up(runs * p.nch, 64);
+        const int tx = runs * X;
+        p.tile_cols = p.halo ? tx - X : tx;
+        p.tiles = ceil_div(out_w, p.tile_cols);
         // One workgroup per CU at a time (its registers fill the CU).  A strip of R rows costs about
         // R + (wh - 1) / 2 + 3 row times (the wh - 1 warm-up rows only add, the prologue is worth ~3 rows) and the
         // chip works through ceil(workgroups / CUs) rounds of them: take the strip count with the cheapest total
@@ -272,30 +291,64 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         // (With 4 disparities per thread and a window up to 9 x 9 the kernel stays within 128 VGPRs: two
         // workgroups share a CU, four waves per SIMD, and a round is twice as many workgroups -- the runtime's
         // occupancy figure where a device is there to ask, that rule of thumb for ws_plan without one.)
-        const int slots = march_slots_per_cu(c, nd, m.threads);
-        double best_cost = 0.0;
-        strips = 1;
-        for (int sc = 1; sc <= out_h; ++sc) {
-            const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
-            if (st != sc) continue; // (the same strips as a smaller count already seen)
-            const int rounds = ceil_div(m.tiles * st, num_cus * slots);
-            const double cost = rounds * (rows + 0.5 * (c.wh - 1) + 3.0);
-            if (sc == 1 || cost < best_cost) { best_cost = cost; strips = sc; }
+        const int slots = march_slots_per_cu(c, nd, p.threads, p.halo != 0);
+        auto strip_cost = [&](int st, int rows) { return ceil_div(p.tiles * st, num_cus * slots) * (rows + 0.5 * (c.wh - 1) + 3.0); };
+        int strips = 1;
+        if (tune_strip_rows > 0) {
+            strips = ceil_div(out_h, tune_strip_rows);
+        } else {
+            double best_cost = 0.0;
+            for (int sc = 1; sc <= out_h; ++sc) {
+                const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
+                if (st != sc) continue; // (the same strips as a smaller count already seen)
+                const double cost = strip_cost(st, rows);
+                if (sc == 1 || cost < best_cost) { best_cost = cost; strips = sc; }
+            }
+            if (strips > out_h) strips = out_h;
         }
-        if (strips > out_h) strips = out_h;
+        p.strip_rows = ceil_div(out_h, strips);
+        p.strips = ceil_div(out_h, p.strip_rows);
+        const int dt = p.nch * nd;
+        const int nreg = X / 4, nregb = march_nreg_b(X, nd);
+        const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
+                  b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
+                  bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);
+        const int nr = c.wh + 2;
+        p.lds_bytes = c.ssd ? (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8
+                            : (size_t)(nr * a_w + nr * b_w) * 4 + (size_t)2 * tx * 4;
+        if (p.lds_bytes > 160 * 1024) return 0.0;
+        // a row step of the halo-exchange kernel against the plain one's, from the instruction counts (march_pk_halo);
+        // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
+        const double step = !p.halo ? 1.0 : c.ww >= 9 ? 0.80 : c.ww == 8 ? 0.81 : c.ww == 7 ? 0.83 : 0.85;
+        return p.passes * (1.0 + 0.02 * (p.passes - 1)) * step * strip_cost(p.strips, p.strip_rows);
+    };
+    m.halo = 0;
+    MarchLaunch best = m;
+    const double plain_cost = complete(best, nxr);
+    // Packed SAD with the halo exchange: the last run of a tile only feeds its neighbour, so tiles want MANY runs --
+    // 16 (a row of DPP lanes; 1/16 of the threads lost) or 8, rather than the 4 .. 8 a wide disparity range leaves
+    // above.  The range is cut into more d-group passes instead: runs x (threads / runs) chunks per pass.  Taken when
+    // the model says it is cheaper than the plain plan.
+    double best_cost = plain_cost;
+    if (find_march_halo(c) && tune_nxr <= 0 && !forced_chunks) {
+        for (int hx : {16, 8}) { // (powers of two: lane + 1 is the next run inside a DPP row)
+            if (need + 1 < hx && hx > 8) continue; // (tiles wider than the image)
+            const int hch = maxt / hx;             // chunks per pass that fill the workgroup
+            if (hch < min_chunks(sh)) continue;
+            MarchLaunch h = m;
+            h.halo = 1;
+            h.passes = ceil_div(nch_total, hch);
+            h.nch = ceil_div(nch_total, h.passes);
+            if (h.nch < min_chunks(sh)) h.nch = min_chunks(sh);
+            const double cost = complete(h, hx);
+            if (cost > 0.0 && (best_cost <= 0.0 || cost < best_cost)) {
+                best = h;
+                best_cost = cost;
+            }
+        }
     }
-    m.strip_rows = ceil_div(out_h, strips);
-    m.strips = ceil_div(out_h, m.strip_rows);
-    const int dt = m.nch * nd;
-    const int nreg = X / 4, nregb = march_nreg_b(X, nd);
-    const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
-              b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
-              bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);
-    const int nr = c.wh + 2;
-    m.lds_bytes = c.ssd ? (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8
-                        : (size_t)(nr * a_w + nr * b_w) * 4 + (size_t)2 * tx * 4;
-    if (m.lds_bytes > 160 * 1024) return false;
-    *out = m;
+    if (best_cost <= 0.0) return false;
+    *out = best;
     return true;
 }
 
@@ -312,11 +365,11 @@ void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane 
     const int tx = m.nxr * m.x_per_thread, dt = m.nch * m.nd_per_thread;
     const int dhi_t = c.d_lo + m.passes * dt - 1; // the last pass reaches furthest to the left
     const int n_a = tx + c.ww - 1, n_b = tx + c.ww + m.passes * dt - 2, n_bi = tx + m.passes * dt - 1;
-    // first column each tile row copy starts at (tile 0); tiles advance by tx (a multiple of 8)
+    // first column each tile row copy starts at (tile 0); tiles advance by tile_cols (a multiple of 8)
     const int base_a = c.ox0 + c.wx0;
     const int base_b = c.ox0 + c.wx0 + c.boff - dhi_t;
     const int base_bi = c.ox0 + c.boff - dhi_t;
-    const int last = (m.tiles - 1) * tx;
+    const int last = (m.tiles - 1) * m.tile_cols;
     a->pad = aligned_pad(base_a);
     a->pitch = round_up(std::max(base_a + last + round_up(n_a, 4), c.wa) + a->pad + 4, 64);
     b->pad = aligned_pad(base_b);
@@ -326,9 +379,9 @@ void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane 
 }
 
 
-const char *march_kernel_name(const Canon &c, const MarchLaunch &)
+const char *march_kernel_name(const Canon &c, const MarchLaunch &m)
 {
-    const MarchEntry *e = find_march(c);
+    const MarchEntry *e = m.halo ? find_march_halo(c) : find_march(c);
     return e ? e->name : "";
 }
 
@@ -336,7 +389,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
                         float *out, double *out64, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
                         hipStream_t s)
 {
-    const MarchEntry *e = find_march(c);
+    const MarchEntry *e = m.halo ? find_march_halo(c) : find_march(c);
     if (!e) return hipErrorInvalidValue;
     MarchArgs g{};
     g.A = a.data;
@@ -369,6 +422,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.oy1 = c.oy1;
     g.strip_rows = m.strip_rows;
     g.tiles = m.tiles;
+    g.tile_stride = m.tile_cols;
     g.strips = m.strips;
     g.prefer_large = c.prefer_large;
     g.mirror = c.mirror;

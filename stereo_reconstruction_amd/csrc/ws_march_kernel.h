@@ -29,6 +29,7 @@ struct MarchArgs {
     int keys_pitch;
     int ox0, ox1, oy0, oy1;
     int strip_rows, tiles, strips;
+    int tile_stride; // output columns per tile: nxr * X, or (nxr - 1) * X for the halo-exchange kernels (march_pk_halo)
     int prefer_large, mirror, fallback_neg;
     int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
     int32_t *cost_out; // optional (smoothFactor passes): the winner's cost, SSD without the sum of a^2
@@ -305,7 +306,93 @@ __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&b
     }
 }
 
-template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false>
+// ---- packed SAD with the window's right-hand part taken from the neighbouring thread ------------------------------
+// march_pk runs every prefix chain over X + WW - 1 positions to get X windows: at 9 x 9 half of its v_sad are spent on
+// columns the thread to the right covers as well.  Here a thread's chains stop after its OWN X columns (T[0 .. X-1]),
+// and the part of window x that lies in the next thread's columns, positions X .. x + WW - 1, is that thread's prefix
+// N[x + WW - 1 - X], fetched with one DPP move per value (row_shl:1: lane + 1 is run r + 1 of the same d-chunk, the
+// planner keeps nxr at 8 or 16 so that a row of 16 lanes holds whole tiles rows):
+//     w[x] = T[X-1] - T[x-1] + N[x + WW - 1 - X]          (w[x] = T[x + WW - 1] - T[x-1] while the window is inside)
+// 32 v_sad + 8 v_pk_sub less and 8 v_mov_dpp + 7 v_pk_add more per pair of disparities at 9 x 9 (X = 8).  The LAST run
+// of a tile has no right-hand neighbour: its windows are wrong and never leave the workgroup -- tiles advance by
+// (nxr - 1) * X columns and the last run only feeds the one before it (it covers exactly that run's window overhang:
+// WW - 1 <= X).  A thread also reads only X pixels of A and X + ND - 1 of B per row instead of X + WW - 1 / X + WW + ND - 2.
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); // row_shl:1 (lane i reads lane i + 1)
+}
+
+template <int X, int ND, int WW, int PHASE, bool MASKED>
+__device__ __forceinline__ void march_pk_halo(uint32_t (&Vp)[X][ND / 2], uint32_t (&best)[X], const uint32_t (&pa)[X],
+                                              const uint32_t (&pb)[X + ND - 1], const uint32_t (&qa)[X],
+                                              const uint32_t (&qb)[X + ND - 1], const uint32_t (&tagr)[ND],
+                                              const uint32_t (&mk)[X + ND - 1])
+{
+    static_assert(WW - 1 <= X && WW >= 2, "the next run covers the whole overhang of a window");
+    constexpr int NN = WW - 1;
+    auto finish = [&](const uint32_t (&T)[X], int j) __attribute__((always_inline)) {
+        uint32_t N[NN];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) N[i] = from_next_lane(T[i]);
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            uint32_t w;
+            if (x + WW - 1 < X) {
+                w = x ? pk_sub(T[x + WW - 1], T[x - 1]) : T[WW - 1];
+            } else {
+                const uint32_t own = x ? pk_sub(T[X - 1], T[x - 1]) : T[X - 1];
+                w = pk_add(own, N[x + WW - 1 - X]);
+            }
+            const uint32_t v = pk_add(Vp[x][j / 2], w);
+            Vp[x][j / 2] = v;
+            if constexpr (PHASE >= 1) {
+                uint32_t k0 = (v << 16) | tagr[j];
+                uint32_t k1 = (v & 0xffff0000u) | tagr[j + 1];
+                if constexpr (MASKED) {
+                    k0 |= mk[x - j + ND - 1];
+                    k1 |= mk[x - j + ND - 2];
+                }
+                if (j == 0) best[x] = min(k0, k1);
+                else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(best[x]) : "v"(best[x]), "v"(k0), "v"(k1));
+            }
+        }
+    };
+    if constexpr (PHASE == 2) {
+#pragma unroll
+        for (int j = 0; j < ND; j += 2) {
+            uint32_t T[X];
+            uint32_t sn = 0, so = 0;
+#pragma unroll
+            for (int i = 0; i < X; ++i) {
+                sn = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 1], sn);
+                so = __builtin_amdgcn_sad_u8(qa[i], qb[i - j + ND - 1], so);
+                sn = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 2], sn);
+                so = __builtin_amdgcn_sad_hi_u8(qa[i], qb[i - j + ND - 2], so);
+                T[i] = pk_sub(sn, so);
+            }
+            finish(T, j);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ND; j += 4) {
+            uint32_t T0[X], T1[X];
+            uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+            for (int i = 0; i < X; ++i) {
+                s0 = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 1], s0);
+                s1 = __builtin_amdgcn_sad_u8(pa[i], pb[i - j + ND - 3], s1);
+                s0 = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 2], s0);
+                s1 = __builtin_amdgcn_sad_hi_u8(pa[i], pb[i - j + ND - 4], s1);
+                T0[i] = s0;
+                T1[i] = s1;
+            }
+            finish(T0, j);
+            finish(T1, j + 2);
+        }
+    }
+}
+
+template <int X, int ND, int WW, int WH, bool SSD, int MAXT, bool COST = false, bool HALO = false>
 __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 {
     static_assert(X % 4 == 0 && ND % 4 == 0, "runs start on 16-byte quads");
@@ -317,6 +404,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
     // (packed SAD: (cost << 16) | global tie tag as an UNSIGNED 32-bit key, cost field 0xffff = no valid candidate)
     constexpr bool PK = !SSD && march_pk_window(WW, WH);
+    static_assert(!HALO || PK, "the halo exchange is the packed SAD kernel's");
     typedef typename std::conditional<SSD, long long, typename std::conditional<PK, uint32_t, int32_t>::type>::type slot_t;
     const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : PK ? (slot_t)0xffffffffu : (slot_t)INT_MAX;
 
@@ -325,7 +413,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
 
     const int NT = blockDim.x, tid = threadIdx.x;
     const int tx = g.nxr * X, dt = g.nch * ND;
-    const int n_a = tx + WW - 1, n_b = tx + WW + dt - 2, n_bi = tx + dt - 1;
+    // pixels of a row the tile's threads read (HALO: nobody reads past the last run's own columns)
+    const int n_a = HALO ? tx : tx + WW - 1, n_b = HALO ? tx + dt - 1 : tx + WW + dt - 2, n_bi = tx + dt - 1;
     const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
     const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
     const int a_w = NREG * ro_a, b_w = NREGB * ro_b, bi_w = NREGB * ro_bi;
@@ -343,7 +432,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int nblk = gridDim.x; // padded to a multiple of 8 by the launcher
     const int logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     if (logical >= g.tiles * g.strips) return; // uniform per workgroup
-    const int tile_x0 = g.ox0 + (logical % g.tiles) * tx;
+    const int tile_x0 = g.ox0 + (logical % g.tiles) * g.tile_stride;
+    const int tx_out = HALO ? tx - X : tx; // the columns this tile hands out (HALO: the last run only feeds its neighbour)
     const int ys = g.oy0 + (logical / g.tiles) * g.strip_rows;
     const int ye = min(ys + g.strip_rows, g.oy1);
     if (ys >= ye) return; // uniform per workgroup
@@ -441,7 +531,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         const uint32_t *rowA = ringA + out_slot * a_w;
         // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
         const int k = tid - (NT - round_up_dev(tx, 64));
-        if (k >= 0 && k < tx) {
+        if (k >= 0 && k < tx_out) {
             const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r] (round 3: [r][x] -- a thread's slots as neighbours, one
                                                     // address for all eight ds_min -- saved 14 instructions a step and lost more to
                                                     // LDS bank conflicts: config 2 0.120 -> 0.125 ms)
@@ -512,14 +602,16 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 uint32_t bestp[X];
 #pragma unroll
                 for (int x = 0; x < X; ++x) bestp[x] = 0xffffffffu;
-                uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2];
-                lds_run<X + WW - 1, NREG>(pa, addA, ro_a);
-                lds_run<X + WW + ND - 2, NREGB>(pb, addB, ro_b);
+                constexpr int NPA = HALO ? X : X + WW - 1, NPB = HALO ? X + ND - 1 : X + WW + ND - 2;
+                uint32_t pa[NPA], pb[NPB], qa[NPA], qb[NPB];
+                lds_run<NPA, NREG>(pa, addA, ro_a);
+                lds_run<NPB, NREGB>(pb, addB, ro_b);
                 if constexpr (PHASE == 2) {
-                    lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
-                    lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
+                    lds_run<NPA, NREG>(qa, subA, ro_a);
+                    lds_run<NPB, NREGB>(qb, subB, ro_b);
                 }
-                march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
+                if constexpr (HALO) march_pk_halo<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
+                else march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
                 if constexpr (PHASE >= 1) {
 #pragma unroll
                     for (int x = 0; x < X; ++x) atomicMin(sl + x * g.nxr, bestp[x]); // ds_min_u32
@@ -629,5 +721,12 @@ static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns wit
 // the instructions saved.  16 x 8 does not fit the register file: 145 spilled registers.)
 // the 4-disparities-per-thread instantiations (ws_march_nd4.hip)
 const MarchEntry *march_table_narrow(int *count);
+// the halo-exchange instantiations of the packed SAD kernel (march_pk_halo): 8 disparities per thread, windows 7 .. 9
+// wide (left view) and 6 .. 8 (right view, with the cost-writing twin); narrower windows have little overhang to save
+#define WS_MARCH_HALO_ENTRY(W, H)                                                                                    \
+    {kX, W, H, 0, kND, ws_march_kernel<kX, kND, W, H, false, kMaxT, false, true>, nullptr, "ws_march_kernel<sad," #W "x" #H ",halo>"}
+#define WS_MARCH_HALO_ENTRY_COST(W, H)                                                                               \
+    {kX, W, H, 0, kND, ws_march_kernel<kX, kND, W, H, false, kMaxT, false, true>,                                    \
+     ws_march_kernel<kX, kND, W, H, false, kMaxT, true, true>, "ws_march_kernel<sad," #W "x" #H ",halo>"}
 
 } // namespace wsamd

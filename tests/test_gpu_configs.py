@@ -33,6 +33,31 @@ def bands(h, half, n):
     return [(half, half + n), (h // 2, h // 2 + n), (h - half - n, h - half)]
 
 
+@pytest.mark.parametrize("view", ["left", "right"])
+def test_config3_full_size_sad_with_the_halo_exchange(wslib, gpu_ctx, oracle, view):
+    """BASELINE.json configs[2] at full size (2964 x 1988, 9x9 SAD, D = 512): the packed SAD kernel whose threads take
+    the right-hand part of their windows from the neighbouring thread -- tiles of 16 runs overlapping by one, the range in
+    four d-group passes meeting in the key plane -- against oracle row bands over the full width (every tile seam)."""
+    import torch
+    w, h, bs, maxd = 2964, 1988, 9, 512
+    half = (bs - 1) // 2
+    left, right, gt = make_pair(w, h, maxd, 33)
+    p = wslib.make_params(wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT, bs, 0, maxd, 1.0, "sad")
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    to = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    gpu_ctx.search_device(p, tl, tr, to, None)
+    torch.cuda.synchronize()
+    info = gpu_ctx.last_launch()
+    assert "halo" in info["kernel"] and info["threads"] == 256, info
+    got = to.cpu().numpy().astype(np.float64)
+    fn = oracle.block_left if view == "left" else oracle.block_right
+    for y0, y1 in bands(h, half, 2):
+        band = fn(left, right, bs, 0, maxd, cost="sad", rows=(y0, y1), threads=8)
+        assert np.array_equal(got[y0:y1], band[y0:y1]), (view, y0)
+    if view == "left":
+        left_view_properties(got, gt, bs, maxd)
+
+
 @pytest.mark.parametrize("dmode", ["D256", "ndisp"])
 def test_config4_training_h_shapes(wslib, gpu_ctx, oracle, dmode):
     """BASELINE.json configs[3]: 15 pairs with the trainingH shapes, 7x7 SSD, D = 256 and D = ndisp

@@ -63,6 +63,36 @@ def test_marching_kernel_matches_oracle(wslib, gpu_ctx, oracle, view, cost, bs):
 
 
 @pytest.mark.parametrize("view", ["left", "right"])
+@pytest.mark.parametrize("bs", [7, 9])
+def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
+    """Packed SAD, windows 6 .. 9 wide: a thread's chains stop after its own 8 columns and the rest of a window comes
+    from the thread to the right (march_pk_halo); tiles overlap by one run and wide ranges take several d-group
+    passes.  Tile edges, image edges (masked candidates), ties, a range wider than the image, min_disparity > 0."""
+    rng = np.random.default_rng(bs)
+    # (shapes the planner gives 8 disparities per thread and the halo plan -- small images take 4 per thread, which has
+    # no such twin; config 3's own band test runs the 16-run, four-pass plan: tests/test_gpu_configs.py)
+    cases = [(700, 40, 0, 300, 256), (700, 40, 20, 300, 3), (1500, 30, 0, 512, 256), (900, 50, 0, 380, 2), (620, 36, 0, 1000, 256)]
+    used = 0
+    for (w, h, dmin, dmax, levels) in cases:
+        if levels == 256:
+            left, right, _ = make_pair(w, h, min(dmax, w // 3), seed=w + bs)
+        else:
+            left = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
+            right = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
+        left[h // 2, w // 3] = 0
+        got = run(wslib, gpu_ctx, view, left, right, bs, dmin, dmax, "sad")
+        used += "halo" in gpu_ctx.last_launch()["kernel"]
+        assert np.array_equal(got, ref(oracle, view, left, right, bs, dmin, dmax, "sad")), (w, h, dmin, dmax, levels)
+    assert used >= 4, used
+    # the other cost and the narrow windows keep the plain kernels
+    left, right, _ = make_pair(331, 75, 70, seed=3)
+    run(wslib, gpu_ctx, view, left, right, bs, 0, 70, "ssd")
+    assert "halo" not in gpu_ctx.last_launch()["kernel"]
+    run(wslib, gpu_ctx, view, left, right, 5, 0, 70, "sad")
+    assert "halo" not in gpu_ctx.last_launch()["kernel"]
+
+
+@pytest.mark.parametrize("view", ["left", "right"])
 @pytest.mark.parametrize("levels", [2, 3])
 def test_ties_follow_the_reference_order(wslib, gpu_ctx, oracle, view, levels):
     # few grey levels -> many exactly equal costs: left keeps the largest d, right the smallest
