@@ -319,7 +319,9 @@ __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&b
 // WW - 1 <= X).  A thread also reads only X pixels of A and X + ND - 1 of B per row instead of X + WW - 1 / X + WW + ND - 2.
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false); // row_shl:1 (lane i reads lane i + 1)
+    // row_shl:1: lane i reads lane i + 1 of its row of 16; the row's last lane reads 0 (bound_ctrl) -- it is a tile's
+    // last run.  (mov_dpp, not update_dpp(0, ...): that one costs a v_mov of the 0 in front of every move)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x101, 0xf, 0xf, true);
 }
 
 template <int X, int ND, int WW, int PHASE, bool MASKED>
@@ -337,8 +339,10 @@ __device__ __forceinline__ void march_pk_halo(uint32_t (&Vp)[X][ND / 2], uint32_
 #pragma unroll
         for (int x = 0; x < X; ++x) {
             uint32_t w;
-            if (x + WW - 1 < X) {
-                w = x ? pk_sub(T[x + WW - 1], T[x - 1]) : T[WW - 1];
+            constexpr int kLastInside = X - WW; // the last column whose window ends inside the thread's own columns (< 0: none)
+            if (x <= kLastInside) {
+                const uint32_t t_hi = T[x <= kLastInside ? x + WW - 1 : 0];
+                w = x ? pk_sub(t_hi, T[x - 1]) : t_hi;
             } else {
                 const uint32_t own = x ? pk_sub(T[X - 1], T[x - 1]) : T[X - 1];
                 w = pk_add(own, N[x + WW - 1 - X]);
