@@ -291,7 +291,8 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         // (With 4 disparities per thread and a window up to 9 x 9 the kernel stays within 128 VGPRs: two
         // workgroups share a CU, four waves per SIMD, and a round is twice as many workgroups -- the runtime's
         // occupancy figure where a device is there to ask, that rule of thumb for ws_plan without one.)
-        const int slots = march_slots_per_cu(c, nd, p.threads, p.halo != 0);
+        const int pnd = p.nd_per_thread;
+        const int slots = march_slots_per_cu(c, pnd, p.threads, p.halo != 0);
         auto strip_cost = [&](int st, int rows) { return ceil_div(p.tiles * st, num_cus * slots) * (rows + 0.5 * (c.wh - 1) + 3.0); };
         int strips = 1;
         if (tune_strip_rows > 0) {
@@ -308,8 +309,8 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         }
         p.strip_rows = ceil_div(out_h, strips);
         p.strips = ceil_div(out_h, p.strip_rows);
-        const int dt = p.nch * nd;
-        const int nreg = X / 4, nregb = march_nreg_b(X, nd);
+        const int dt = p.nch * pnd;
+        const int nreg = X / 4, nregb = march_nreg_b(X, pnd);
         const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
                   b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
                   bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);
@@ -319,7 +320,9 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         if (p.lds_bytes > 160 * 1024) return 0.0;
         // a row step of the halo-exchange kernel against the plain one's, from the instruction counts (march_pk_halo);
         // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
-        const double step = !p.halo ? 1.0 : c.ww >= 9 ? 0.80 : c.ww == 8 ? 0.81 : c.ww == 7 ? 0.83 : 0.85;
+        // (6.19 against 7.52 instructions per hypothesis at 9 x 9, profiles/r03/isa_op_histogram.txt; a thread of the halo
+        // kernels carries kNDHalo / nd times the hypotheses)
+        const double step = !p.halo ? 1.0 : (c.ww >= 9 ? 0.82 : c.ww == 8 ? 0.83 : c.ww == 7 ? 0.85 : 0.87) * kNDHalo / nd;
         return p.passes * (1.0 + 0.02 * (p.passes - 1)) * step * strip_cost(p.strips, p.strip_rows);
     };
     m.halo = 0;
@@ -337,8 +340,10 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
             if (hch < min_chunks(sh)) continue;
             MarchLaunch h = m;
             h.halo = 1;
-            h.passes = ceil_div(nch_total, hch);
-            h.nch = ceil_div(nch_total, h.passes);
+            h.nd_per_thread = kNDHalo;
+            const int hch_total = ceil_div(dcount, kNDHalo);
+            h.passes = ceil_div(hch_total, hch);
+            h.nch = ceil_div(hch_total, h.passes);
             if (h.nch < min_chunks(sh)) h.nch = min_chunks(sh);
             const double cost = complete(h, hx);
             if (cost > 0.0 && (best_cost <= 0.0 || cost < best_cost)) {

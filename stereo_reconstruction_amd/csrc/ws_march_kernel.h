@@ -243,11 +243,28 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
 }
 
 // PHASE 0: a row enters, no keys.  1: a row enters, keys.  2: a row enters, a row leaves (qa / qb), keys.
+// Which of a thread's candidates have their target centre inside [b_lo, b_hi]: centre of (x, j) = xb0 + m with
+// m = x - j + ND - 1, valid iff mlo <= m <= mlo + span.  Two registers and a compare per key in the few waves that need it
+// (a table of X + ND - 1 masks cost the 16-disparity kernels 50 spilled registers).
+struct PkMask {
+    int mlo;
+    uint32_t span;
+    __device__ __forceinline__ uint32_t operator()(int m) const { return (uint32_t)(m - mlo) > span ? kPkNone : 0u; }
+    // called once per row step: the masks are loop invariant, and hoisted out of the row loop they are X + ND - 1
+    // registers again -- the empty asm makes them the step's own
+    __device__ __forceinline__ PkMask fresh() const
+    {
+        PkMask f = *this;
+        asm volatile("" : "+v"(f.mlo));
+        return f;
+    }
+};
+
 template <int X, int ND, int WW, int PHASE, bool MASKED>
 __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&best)[X], const uint32_t (&pa)[X + WW - 1],
                                          const uint32_t (&pb)[X + WW + ND - 2], const uint32_t (&qa)[X + WW - 1],
                                          const uint32_t (&qb)[X + WW + ND - 2], const uint32_t (&tagr)[ND],
-                                         const uint32_t (&mk)[X + ND - 1])
+                                         const PkMask mk)
 {
     constexpr int NA = X + WW - 1;
     auto finish = [&](const uint32_t (&T)[NA], int j) __attribute__((always_inline)) {
@@ -260,8 +277,8 @@ __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&b
                 uint32_t k0 = (v << 16) | tagr[j];              // disparity j      (v_lshl_or_b32)
                 uint32_t k1 = (v & 0xffff0000u) | tagr[j + 1];  // disparity j + 1  (v_and_or_b32)
                 if constexpr (MASKED) {
-                    k0 |= mk[x - j + ND - 1];
-                    k1 |= mk[x - j + ND - 2];
+                    k0 |= mk(x - j + ND - 1);
+                    k1 |= mk(x - j + ND - 2);
                 }
                 // (spelled out: the compiler splits min(best, min(k0, k1)) into two v_min_u32 for a third of the columns)
                 if (j == 0) best[x] = min(k0, k1); // (the first pair of a step: nothing to compare with yet)
@@ -328,7 +345,7 @@ template <int X, int ND, int WW, int PHASE, bool MASKED>
 __device__ __forceinline__ void march_pk_halo(uint32_t (&Vp)[X][ND / 2], uint32_t (&best)[X], const uint32_t (&pa)[X],
                                               const uint32_t (&pb)[X + ND - 1], const uint32_t (&qa)[X],
                                               const uint32_t (&qb)[X + ND - 1], const uint32_t (&tagr)[ND],
-                                              const uint32_t (&mk)[X + ND - 1])
+                                              const PkMask mk)
 {
     static_assert(WW - 1 <= X && WW >= 2, "the next run covers the whole overhang of a window");
     constexpr int NN = WW - 1;
@@ -353,8 +370,8 @@ __device__ __forceinline__ void march_pk_halo(uint32_t (&Vp)[X][ND / 2], uint32_
                 uint32_t k0 = (v << 16) | tagr[j];
                 uint32_t k1 = (v & 0xffff0000u) | tagr[j + 1];
                 if constexpr (MASKED) {
-                    k0 |= mk[x - j + ND - 1];
-                    k1 |= mk[x - j + ND - 2];
+                    k0 |= mk(x - j + ND - 1);
+                    k1 |= mk(x - j + ND - 2);
                 }
                 if (j == 0) best[x] = min(k0, k1);
                 else asm("v_min3_u32 %0, %1, %2, %3" : "=v"(best[x]) : "v"(best[x]), "v"(k0), "v"(k1));
@@ -461,7 +478,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int ctag = g.prefer_large ? g.d_top - d0 - (ND - 1) : d0 - g.d_lo;
 
     int32_t V[PK ? 1 : X][PK ? 1 : ND];
-    uint32_t Vp[PK ? X : 1][PK ? ND / 2 : 1], tagr[PK ? ND : 1], mk[PK ? X + ND - 1 : 1];
+    uint32_t Vp[PK ? X : 1][PK ? ND / 2 : 1], tagr[PK ? ND : 1];
+    PkMask mk{0, 0u};
     bool masked = false; // packed SAD: does this WAVE hold candidates whose target centre is out of range next to valid ones?
     if constexpr (PK) {
 #pragma unroll
@@ -476,8 +494,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         }
         // target centre of (x, j): tile_x0 + r X + x - (d0 + j) + boff, i.e. xb0 + m with m = x - j + ND - 1
         const int xb0 = tile_x0 + r * X - d0 + g.boff - (ND - 1);
-#pragma unroll
-        for (int m = 0; m < X + ND - 1; ++m) mk[m] = (xb0 + m >= g.b_lo && xb0 + m <= g.b_hi) ? 0u : kPkNone;
+        mk.mlo = g.b_lo - xb0;
+        mk.span = (uint32_t)(g.b_hi - g.b_lo);
+        if (g.b_hi < g.b_lo) { mk.mlo = 1 << 30; mk.span = 0u; } // (no valid centre at all)
         // Per WAVE: a thread all of whose target centres are out of range poisons its tags instead (free), so only the
         // waves that hold a thread with SOME centres out of range -- the few on the diagonal x - d = b_lo of a tile at
         // the image's edge -- pay the extra v_or per key.  (Wave-uniform: different waves of a workgroup then run
@@ -614,8 +633,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     lds_run<NPA, NREG>(qa, subA, ro_a);
                     lds_run<NPB, NREGB>(qb, subB, ro_b);
                 }
-                if constexpr (HALO) march_pk_halo<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
-                else march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mk);
+                const PkMask mks = MASKED ? mk.fresh() : mk;
+                if constexpr (HALO) march_pk_halo<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mks);
+                else march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mks);
                 if constexpr (PHASE >= 1) {
 #pragma unroll
                     for (int x = 0; x < X; ++x) atomicMin(sl + x * g.nxr, bestp[x]); // ds_min_u32
@@ -725,12 +745,16 @@ static_assert(kX <= 8, "the flush of ws_march_kernel covers a tile's columns wit
 // the instructions saved.  16 x 8 does not fit the register file: 145 spilled registers.)
 // the 4-disparities-per-thread instantiations (ws_march_nd4.hip)
 const MarchEntry *march_table_narrow(int *count);
-// the halo-exchange instantiations of the packed SAD kernel (march_pk_halo): 8 disparities per thread, windows 7 .. 9
-// wide (left view) and 6 .. 8 (right view, with the cost-writing twin); narrower windows have little overhang to save
+// the halo-exchange instantiations of the packed SAD kernel (march_pk_halo): 16 disparities per thread (8 packed
+// running sums per column: tiles of 16 runs then hold 512 disparities in 512 threads -- with 8 per thread a range
+// that wide took several d-group passes, each a round trip of the key plane), windows 7 .. 9 wide (left view) and
+// 6 .. 8 (right view, with the cost-writing twin); narrower windows have little overhang to save
+constexpr int kNDHalo = 16;
 #define WS_MARCH_HALO_ENTRY(W, H)                                                                                    \
-    {kX, W, H, 0, kND, ws_march_kernel<kX, kND, W, H, false, kMaxT, false, true>, nullptr, "ws_march_kernel<sad," #W "x" #H ",halo>"}
+    {kX, W, H, 0, kNDHalo, ws_march_kernel<kX, kNDHalo, W, H, false, kMaxT, false, true>, nullptr,                   \
+     "ws_march_kernel<sad," #W "x" #H ",halo>"}
 #define WS_MARCH_HALO_ENTRY_COST(W, H)                                                                               \
-    {kX, W, H, 0, kND, ws_march_kernel<kX, kND, W, H, false, kMaxT, false, true>,                                    \
-     ws_march_kernel<kX, kND, W, H, false, kMaxT, true, true>, "ws_march_kernel<sad," #W "x" #H ",halo>"}
+    {kX, W, H, 0, kNDHalo, ws_march_kernel<kX, kNDHalo, W, H, false, kMaxT, false, true>,                            \
+     ws_march_kernel<kX, kNDHalo, W, H, false, kMaxT, true, true>, "ws_march_kernel<sad," #W "x" #H ",halo>"}
 
 } // namespace wsamd

@@ -36,8 +36,8 @@ def bands(h, half, n):
 @pytest.mark.parametrize("view", ["left", "right"])
 def test_config3_full_size_sad_with_the_halo_exchange(wslib, gpu_ctx, oracle, view):
     """BASELINE.json configs[2] at full size (2964 x 1988, 9x9 SAD, D = 512): the packed SAD kernel whose threads take
-    the right-hand part of their windows from the neighbouring thread -- tiles of 16 runs overlapping by one, the range in
-    four d-group passes meeting in the key plane -- against oracle row bands over the full width (every tile seam)."""
+    the right-hand part of their windows from the neighbouring thread -- tiles of 16 runs overlapping by one, 16 disparities
+    per thread: the 512 candidates in one pass -- against oracle row bands over the full width (every tile seam)."""
     import torch
     w, h, bs, maxd = 2964, 1988, 9, 512
     half = (bs - 1) // 2
@@ -48,7 +48,7 @@ def test_config3_full_size_sad_with_the_halo_exchange(wslib, gpu_ctx, oracle, vi
     gpu_ctx.search_device(p, tl, tr, to, None)
     torch.cuda.synchronize()
     info = gpu_ctx.last_launch()
-    assert "halo" in info["kernel"] and info["threads"] == 256, info
+    assert "halo" in info["kernel"] and info["threads"] == 512, info
     got = to.cpu().numpy().astype(np.float64)
     fn = oracle.block_left if view == "left" else oracle.block_right
     for y0, y1 in bands(h, half, 2):

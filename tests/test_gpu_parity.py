@@ -66,12 +66,24 @@ def test_marching_kernel_matches_oracle(wslib, gpu_ctx, oracle, view, cost, bs):
 @pytest.mark.parametrize("bs", [7, 9])
 def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
     """Packed SAD, windows 6 .. 9 wide: a thread's chains stop after its own 8 columns and the rest of a window comes
-    from the thread to the right (march_pk_halo); tiles overlap by one run and wide ranges take several d-group
-    passes.  Tile edges, image edges (masked candidates), ties, a range wider than the image, min_disparity > 0."""
+    from the thread to the right (march_pk_halo, 16 disparities per thread); tiles overlap by one run.  The planner
+    takes that kernel where the chip is full (a small search is quicker with the plain one's wider workgroups), so the
+    images here are large and the oracle checks row bands over the full width: every tile seam, the image's left edge
+    (masked candidates), ties (few grey levels), two d-group passes, 8 runs per tile."""
+    import torch
     rng = np.random.default_rng(bs)
-    # (shapes the planner gives 8 disparities per thread and the halo plan -- small images take 4 per thread, which has
-    # no such twin; config 3's own band test runs the 16-run, four-pass plan: tests/test_gpu_configs.py)
-    cases = [(700, 40, 0, 300, 256), (700, 40, 20, 300, 3), (1500, 30, 0, 512, 256), (900, 50, 0, 380, 2), (620, 36, 0, 1000, 256)]
+
+    def on_device(left, right, bs_, dmin, dmax, cost):
+        # (device-resident: the host calls cut a large pair into row bands, each a small search of its own)
+        p = wslib.make_params(wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT, bs_, dmin, dmax, 1.0, cost)
+        ref_img = left if view == "left" else right
+        to = torch.empty(ref_img.shape[:2], dtype=torch.float32, device="cuda")
+        gpu_ctx.search_device(p, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), to, None)
+        torch.cuda.synchronize()
+        return to.cpu().numpy().astype(np.float64)
+
+    cases = [(2000, 600, 0, 512, 256), (2400, 300, 0, 512, 3), (2000, 600, 0, 500, 2), (3000, 400, 0, 1024, 256), (2600, 500, 40, 552, 256)]
+    half = (bs - 1) // 2
     used = 0
     for (w, h, dmin, dmax, levels) in cases:
         if levels == 256:
@@ -80,15 +92,18 @@ def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
             left = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
             right = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
         left[h // 2, w // 3] = 0
-        got = run(wslib, gpu_ctx, view, left, right, bs, dmin, dmax, "sad")
-        used += "halo" in gpu_ctx.last_launch()["kernel"]
-        assert np.array_equal(got, ref(oracle, view, left, right, bs, dmin, dmax, "sad")), (w, h, dmin, dmax, levels)
-    assert used >= 4, used
+        got = on_device(left, right, bs, dmin, dmax, "sad")
+        used += "halo" in gpu_ctx.last_launch()["kernel"]      # (the planner picks it for three to five of these)
+        fn = oracle.block_left if view == "left" else oracle.block_right
+        for y0 in (half, h // 2, h - half - 2):
+            band = fn(left, right, bs, dmin, dmax, cost="sad", rows=(y0, y0 + 2), threads=8)
+            assert np.array_equal(got[y0:y0 + 2], band[y0:y0 + 2]), (w, h, dmin, dmax, levels, y0)
+    assert used >= 3, used
     # the other cost and the narrow windows keep the plain kernels
-    left, right, _ = make_pair(331, 75, 70, seed=3)
-    run(wslib, gpu_ctx, view, left, right, bs, 0, 70, "ssd")
+    left, right, _ = make_pair(2000, 600, 200, seed=3)
+    on_device(left, right, bs, 0, 512, "ssd")
     assert "halo" not in gpu_ctx.last_launch()["kernel"]
-    run(wslib, gpu_ctx, view, left, right, 5, 0, 70, "sad")
+    on_device(left, right, 5, 0, 512, "sad")
     assert "halo" not in gpu_ctx.last_launch()["kernel"]
 
 

@@ -48,8 +48,11 @@ def main():
     m = {c: sum(v) / len(v) * (per_search if c in extensive else 1) for c, v in agg[k].items()}
     t = re.search(r"ws_march_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", k)
     # (the name the library reports: ",nd4" marks the instantiation with 4 disparities per thread)
-    name = "ws_march_kernel<%s,%sx%s%s>" % ("ssd" if t.group(5) == "true" else "sad", t.group(3), t.group(4),
-                                            ",nd4" if t.group(2) == "4" else "")
+    # (",halo": the packed SAD kernel with the halo exchange, the template's last argument)
+    halo = re.search(r"ws_march_kernel<[^>]*, (true|false), (true|false)>", k)
+    name = "ws_march_kernel<%s,%sx%s%s%s>" % ("ssd" if t.group(5) == "true" else "sad", t.group(3), t.group(4),
+                                              ",nd4" if t.group(2) == "4" else "",
+                                              ",halo" if halo and halo.group(2) == "true" else "")
     peak, peak_src = None, None
     if ubench and os.path.exists(ubench):
         rates = [float(x) for x in re.findall(r"march-mix \w+\s+waves/SIMD=\d+ :.*?([\d.]+) Tlane-op/s", open(ubench).read())]
