@@ -77,7 +77,10 @@ struct BiasArgs {
     int32_t *bias;
 };
 
-constexpr int kBiasRows = 16; // output rows per chunk (8 / 16 / 32 measured at config 2 in round 2: 16.3 / 14.6 / 15.5 us for the launch)
+#ifndef WS_BIAS_ROWS
+#define WS_BIAS_ROWS 16
+#endif
+constexpr int kBiasRows = WS_BIAS_ROWS; // (round 3, a workgroup walking a strip chunk by chunk: 16 / 24 / 32 / 48 -> 2.91 / 2.86 / 2.77 / 2.77 * 10^6 Mdisp/s in flight at config 2) output rows per chunk (8 / 16 / 32 measured at config 2 in round 2: 16.3 / 14.6 / 15.5 us for the launch)
 constexpr int kBiasMaxWh = 17; // tallest (and widest) window with a marching instantiation
 constexpr int kBiasStage = kBiasRows + kBiasMaxWh - 1;
 

@@ -107,6 +107,39 @@ def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
     assert "halo" not in gpu_ctx.last_launch()["kernel"]
 
 
+def test_right_view_smooth_factor_on_the_halo_cost_kernel(wslib, gpu_ctx, oracle):
+    """smoothFactor 0.9 in the right view (main.cpp:40) wants the winners' costs from the search: at 9 x 9 SAD on a large
+    pair that is the cost-writing twin of the halo-exchange kernel (window 8 x 8).  The first rows against the oracle (the
+    recurrence runs down from the top), the whole map against the plain kernel's (forced by a tile width of the caller's)."""
+    import torch
+    w, h, maxd = 2400, 160, 512
+    left, right, _ = make_pair(w, h, 300, seed=77)
+    right[8:12, 500:900] = right[8, 500]                    # a flat patch: equal costs, zeros for the factor to act on
+    right[90:94, 1500:1900] = right[90, 1500]
+    p = wslib.make_params(wslib.VIEW_RIGHT, 9, 0, maxd, 0.9, "sad")
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+
+    def search():
+        to = torch.empty((h, w), dtype=torch.float32, device="cuda")
+        gpu_ctx.search_device(p, tl, tr, to, None)
+        torch.cuda.synchronize()
+        return to.cpu().numpy().astype(np.float64), gpu_ctx.last_launch()["kernel"]
+
+    got, kernel = search()
+    assert "halo" in kernel, kernel
+    want = oracle.block_right(left, right, 9, 0, maxd, smooth=0.9, cost="sad", threads=8, rows=(0, 20))
+    assert np.array_equal(got[:20], want[:20])
+    plain = oracle.block_right(left, right, 9, 0, maxd, smooth=1.0, cost="sad", threads=8, rows=(0, 20))
+    assert (want[:20] != plain[:20]).any()                    # the factor did change pixels
+    gpu_ctx.set_tuning(x_runs_per_tile=8)                     # a caller's tile width: the plain kernel
+    try:
+        other, kernel = search()
+    finally:
+        gpu_ctx.set_tuning()
+    assert "halo" not in kernel, kernel
+    assert np.array_equal(got, other)
+
+
 @pytest.mark.parametrize("view", ["left", "right"])
 @pytest.mark.parametrize("levels", [2, 3])
 def test_ties_follow_the_reference_order(wslib, gpu_ctx, oracle, view, levels):

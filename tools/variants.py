@@ -44,8 +44,8 @@ def run(workloads):
                                 "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--check"], env=env, capture_output=True, text=True)
             try:
                 j = json.loads(r.stdout.strip().split("\n")[-1])
-                print("%-28s %-8s %10.0f Mdisp/s  step %.3f ms  kernel %.3f ms  check=%s" % (
-                    f, wl, j["value"], j["ms_per_step"], j["roofline"]["kernel_ms"], j.get("check_rows_equal")), flush=True)
+                print("%-36s %-8s %10.0f Mdisp/s in flight  %10.0f alone  step %.3f ms  kernel %.3f ms  check=%s" % (
+                    f, wl, j["value"], j.get("value_single_pair") or 0, j["ms_per_step"], j["roofline"]["kernel_ms"], j.get("check_rows_equal")), flush=True)
             except Exception as e:
                 print(f, wl, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
 
