@@ -332,9 +332,14 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
     // 16 (a row of DPP lanes; 1/16 of the threads lost) or 8, rather than the 4 .. 8 a wide disparity range leaves
     // above.  The range is cut into more d-group passes instead: runs x (threads / runs) chunks per pass.  Taken when
     // the model says it is cheaper than the plain plan.
+    // (a caller's tile width of 8 or 16 runs -- tools/sweep_tiles.py -- means the halo kernel with that many runs; any
+    // other width the plain one)
     double best_cost = plain_cost;
-    if (find_march_halo(c) && tune_nxr <= 0 && !forced_chunks) {
+    const bool tuned_halo = tune_nxr == 16 || tune_nxr == 8;
+    if (find_march_halo(c) && (tune_nxr <= 0 || tuned_halo) && !forced_chunks) {
+        if (tuned_halo) best_cost = 0.0;
         for (int hx : {16, 8}) { // (powers of two: lane + 1 is the next run inside a DPP row)
+            if (tuned_halo && hx != tune_nxr) continue;
             if (need + 1 < hx && hx > 8) continue; // (tiles wider than the image)
             const int hch = maxt / hx;             // chunks per pass that fill the workgroup
             if (hch < min_chunks(sh)) continue;
@@ -351,6 +356,9 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
                 best_cost = cost;
             }
         }
+    }
+    if (best_cost <= 0.0 && plain_cost > 0.0) { // (the tuned halo plan does not fit: the plain one)
+        best_cost = plain_cost;
     }
     if (best_cost <= 0.0) return false;
     *out = best;

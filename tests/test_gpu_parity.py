@@ -131,7 +131,7 @@ def test_right_view_smooth_factor_on_the_halo_cost_kernel(wslib, gpu_ctx, oracle
     assert np.array_equal(got[:20], want[:20])
     plain = oracle.block_right(left, right, 9, 0, maxd, smooth=1.0, cost="sad", threads=8, rows=(0, 20))
     assert (want[:20] != plain[:20]).any()                    # the factor did change pixels
-    gpu_ctx.set_tuning(x_runs_per_tile=8)                     # a caller's tile width: the plain kernel
+    gpu_ctx.set_tuning(x_runs_per_tile=12)                    # a caller's tile width other than 8 / 16 runs: the plain kernel
     try:
         other, kernel = search()
     finally:
