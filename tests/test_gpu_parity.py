@@ -107,6 +107,44 @@ def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
     assert "halo" not in gpu_ctx.last_launch()["kernel"]
 
 
+def test_halo_and_plain_sad_kernels_agree_on_random_large_pairs(wslib, gpu_ctx):
+    """Differential: the planner's own choice (the halo-exchange kernel wherever its model prefers it) against the plain
+    packed kernel forced by a caller's tile width, whole maps, random large shapes / ranges / views / grey levels and
+    both workgroup sizes -- no oracle needed, so the pairs can be large; the plain kernel is the one the oracle tests pin."""
+    import torch
+    rng = np.random.default_rng(2026)
+    used = 0
+    for case in range(24):
+        w, h = int(rng.integers(1300, 3000)), int(rng.integers(300, 1100))
+        bs = int(rng.choice([7, 9]))
+        view = wslib.VIEW_LEFT if rng.random() < 0.5 else wslib.VIEW_RIGHT
+        dmin = int(rng.choice([0, 0, 13]))
+        dmax = dmin + int(rng.choice([256, 400, 512, 512, 512, 777, 1024]))
+        levels = int(rng.choice([256, 256, 4]))
+        threads = int(rng.choice([0, 0, 256]))
+        if levels == 256:
+            left, right, _ = make_pair(w, h, min(dmax, w // 3), seed=case)
+        else:
+            left = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
+            right = (rng.integers(0, levels, size=(h, w, 3)) * (255 // (levels - 1))).astype(np.uint8)
+        p = wslib.make_params(view, bs, dmin, dmax, 1.0, "sad")
+        tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        maps = []
+        try:
+            for x_runs in (0, 12):                            # 12 runs per tile: never the halo kernel
+                gpu_ctx.set_tuning(x_runs_per_tile=x_runs, threads=threads)
+                to = torch.empty((h, w), dtype=torch.float32, device="cuda")
+                gpu_ctx.search_device(p, tl, tr, to, None)
+                torch.cuda.synchronize()
+                maps.append((to.cpu().numpy(), gpu_ctx.last_launch()["kernel"]))
+        finally:
+            gpu_ctx.set_tuning()
+        assert "halo" not in maps[1][1], maps[1][1]
+        used += "halo" in maps[0][1]
+        assert np.array_equal(maps[0][0], maps[1][0]), (case, w, h, bs, view, dmin, dmax, levels, threads, maps[0][1])
+    assert used >= 6, used
+
+
 def test_right_view_smooth_factor_on_the_halo_cost_kernel(wslib, gpu_ctx, oracle):
     """smoothFactor 0.9 in the right view (main.cpp:40) wants the winners' costs from the search: at 9 x 9 SAD on a large
     pair that is the cost-writing twin of the halo-exchange kernel (window 8 x 8).  The first rows against the oracle (the
