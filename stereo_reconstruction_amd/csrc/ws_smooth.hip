@@ -586,6 +586,95 @@ __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs 
     left_store_entry(g, top + ((size_t)y * top_pitch + x) * kTopWords, c0, d0, c1, d1, c2, d2);
 }
 
+// ---- the same three, separably (round 3) ----------------------------------------------------------------------
+// ws_left_top3_kernel sums a whole window per (pixel, disparity): bs^2 pixel costs each, 13 ms at 17 x 17, D = 200,
+// 900 x 750.  A window cost is a box sum of per-pixel costs, so: for a slab of kTopSlab disparities (descending, the
+// reference's order) ws_left_top3_rows_kernel writes the bs-wide ROW sums of every (row, column, d) of the slab,
+// ws_left_top3_cols_kernel adds bs of them down a column and feeds the pixel's running best three -- kept in the
+// top-3 buffer between slabs, the distances taken after the last one.  2 bs instead of bs^2 pixel costs per
+// candidate; the same integers, so the same three candidates in the same order.
+constexpr int kTopSlab = 8;
+
+// cost of the bs pixels (xl - half .. xl + half, row r) of the left image against the same run at xl - d of the right
+__device__ __forceinline__ uint32_t left_row_cost(const SmoothLeftArgs &g, int xl, int r, int d, int half)
+{
+    if (g.A) {
+        const uint32_t *pa = g.A + (size_t)r * g.pitch_a + (xl - half + g.pad_a);
+        const uint32_t *pb = g.B + (size_t)r * g.pitch_b + (xl - d - half + g.pad_b);
+        if (g.ssd) {
+            uint32_t aa = 0, bb = 0, ab = 0;
+            if (g.centred) {
+                for (int i = 0; i < g.block_size; ++i) {
+                    const uint32_t a = pa[i], b = pb[i];
+                    aa = pix_dot<true>(a, a, aa); bb = pix_dot<true>(b, b, bb); ab = pix_dot<true>(a, b, ab);
+                }
+            } else {
+                for (int i = 0; i < g.block_size; ++i) {
+                    const uint32_t a = pa[i], b = pb[i];
+                    aa = pix_dot<false>(a, a, aa); bb = pix_dot<false>(b, b, bb); ab = pix_dot<false>(a, b, ab);
+                }
+            }
+            return (uint32_t)((int32_t)aa + (int32_t)bb - 2 * (int32_t)ab); // (>= 0: a sum of squares)
+        }
+        uint32_t acc = 0;
+        for (int i = 0; i < g.block_size; ++i) acc = pix_sad(pa[i], pb[i], acc);
+        return acc;
+    }
+    return window_cost(g.L + (size_t)r * g.s1 + 3 * (xl - half), g.s1, g.R + (size_t)r * g.s2 + 3 * (xl - d - half), g.s2,
+                       g.block_size, 1, g.ssd);
+}
+
+// vol[(s * rows + r) * w1 + x] = row sum of (row r, column x, disparity d_top - s); grid (columns, rows, slab)
+__global__ void __launch_bounds__(256) ws_left_top3_rows_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ vol, int rows,
+                                                                int d_top)
+{
+    const int half = (g.block_size - 1) / 2;
+    const int x = half + blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y, d = d_top - (int)blockIdx.z;
+    if (x >= g.w1 - half || !left_candidate_ok(g, x, d, half)) return; // (nobody reads the sums of a candidate that is none)
+    vol[((size_t)blockIdx.z * rows + r) * g.w1 + x] = left_row_cost(g, x, r, d, half);
+}
+
+__global__ void __launch_bounds__(256) ws_left_top3_cols_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ vol, int rows,
+                                                                int d_top, int nslab, int first, int last,
+                                                                uint32_t *__restrict__ top, int top_pitch)
+{
+    const int half = (g.block_size - 1) / 2;
+    const int x = half + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = half + blockIdx.y;
+    if (x >= g.w1 - half) return;
+    uint32_t *t = top + ((size_t)y * top_pitch + x) * kTopWords;
+    uint32_t c0 = kTopNone, c1 = kTopNone, c2 = kTopNone;
+    int d0 = 0, d1 = 0, d2 = 0;
+    if (!first) {
+        c0 = t[0]; d0 = (int)t[1]; c1 = t[4]; d1 = (int)t[5]; c2 = t[8]; d2 = (int)t[9];
+    }
+    if (!black3(g.L + (size_t)y * g.s1 + 3 * x)) {
+        const int d_hi = min(g.max_d, x - half);
+        const int d_lo = max(1, x - (g.w2 - half) + 1);
+        for (int sl = 0; sl < nslab; ++sl) {
+            const int d = d_top - sl; // descending: the reference's order
+            if (d > d_hi) continue;
+            if (d < d_lo) break;
+            const uint32_t *col = vol + ((size_t)sl * rows + (y - half)) * g.w1 + x;
+            uint32_t c = 0;
+            for (int k = 0; k < g.block_size; ++k) c += col[(size_t)k * g.w1];
+            if (c < c2) { // strict: an equal cost met later (smaller d) stays behind
+                if (c < c1) {
+                    c2 = c1; d2 = d1;
+                    if (c < c0) { c1 = c0; d1 = d0; c0 = c; d0 = d; }
+                    else { c1 = c; d1 = d; }
+                } else { c2 = c; d2 = d; }
+            }
+        }
+    }
+    if (last) {
+        left_store_entry(g, t, c0, d0, c1, d1, c2, d2);
+    } else {
+        t[0] = c0; t[1] = (uint32_t)d0; t[4] = c1; t[5] = (uint32_t)d1; t[8] = c2; t[9] = (uint32_t)d2;
+    }
+}
+
 // the reference's running minimum: 'min' starts at DBL_MAX with no winner, d descending, strict '<'
 struct LeftBest {
     double dist;
@@ -1098,7 +1187,12 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
 static size_t smooth_left_edge_pitch(int w) { return (size_t)((w + 15) & ~15); }
 static size_t smooth_left_sync_bytes(int w, int h) { return 64 + ((size_t)h / kBandRows + 2) * smooth_left_edge_pitch(w) * 8; }
 
-size_t smooth_left_top_bytes(int w, int h) { return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h); }
+// (+ the row sums of one slab of disparities, for the factors outside [0, 1])
+static size_t smooth_left_vol_bytes(int w, int h) { return (size_t)kTopSlab * w * h * sizeof(uint32_t); }
+size_t smooth_left_top_bytes(int w, int h)
+{
+    return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h) + smooth_left_vol_bytes(w, h);
+}
 
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
                               unsigned int *gave_up, hipStream_t st)
@@ -1125,10 +1219,33 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     if (iw <= 0 || ih <= 0) return hipSuccess;
     if (s >= 0.0 && s <= 1.0)
         hipLaunchKernelGGL(ws_left_cost_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
-    else
-        hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
-    // hand-off words all ones ("not there yet"), ticket and error words zero
     uint8_t *sync = reinterpret_cast<uint8_t *>(top3) + (size_t)g.w1 * g.h1 * kTopWords * sizeof(uint32_t);
+    if (!(s >= 0.0 && s <= 1.0)) {
+        static const bool whole_windows = [] {
+            const char *e = getenv("WS_TOP3_WHOLE"); // development knob: 1 = the round-2 kernel (whole windows per candidate)
+            return e && atoi(e) == 1;
+        }();
+        if (whole_windows) {
+            hipLaunchKernelGGL(ws_left_top3_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, top3, g.w1);
+        } else {
+            uint32_t *vol = reinterpret_cast<uint32_t *>(sync + smooth_left_sync_bytes(g.w1, g.h1));
+            const int rows = ih + 2 * half; // image rows 0 .. rows - 1 carry the windows of the interior
+            const int d_max = std::min(g.max_d, g.w1 - 1 - 2 * half); // (beyond: no column has such a candidate)
+            int d_top = d_max;
+            bool first = true, last = false;
+            do { // (no candidate anywhere -- d_max < 1 -- still runs once: the entries say "none")
+                const int nslab = std::max(0, std::min(kTopSlab, d_top));
+                last = d_top - kTopSlab < 1;
+                if (nslab > 0)
+                    hipLaunchKernelGGL(ws_left_top3_rows_kernel, dim3(ceil_div(iw, 256), rows, nslab), dim3(256), 0, st, a, vol, rows, d_top);
+                hipLaunchKernelGGL(ws_left_top3_cols_kernel, dim3(ceil_div(iw, 256), ih), dim3(256), 0, st, a, vol, rows, d_top, nslab,
+                                   first ? 1 : 0, last ? 1 : 0, top3, g.w1);
+                first = false;
+                d_top -= kTopSlab;
+            } while (!last);
+        }
+    }
+    // hand-off words all ones ("not there yet"), ticket and error words zero
     const int nbands = ceil_div(ih, kBandRows);
     const size_t pitch = smooth_left_edge_pitch(g.w1);
     hipError_t e = hipMemsetAsync(sync + 64, 0xff, (size_t)(nbands + 1) * pitch * 8, st);
