@@ -13,6 +13,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <fstream>
 #include <mutex>
 #include <string>
@@ -135,8 +137,27 @@ struct HostSpan {
 // Classify and register the buffers of one call.  Spans with p == nullptr or n == 0 stay kUnused.
 // may_register: false for buffers that stay attached while the CALLER'S code runs (ws_enqueue_host ... ws_wait): those
 // are never registered, see ws_enqueue_host.
+// hipHostRegister on the caller's pageable buffers for the duration of a call saves a host copy each way (config 2:
+// 0.39 instead of the staged figure in DESIGN.md 3.5), and every sequence of calls the probe ran was clean
+// (tools/ubench/hostreg_probe.hip).  But twice in round 3 a full test run -- hundreds of register / unregister cycles
+// on heap pages that numpy and PyTorch reuse for their own pageable copies -- ended in a GPU memory fault on a HOST heap
+// address long after the last registration was released (the second time inside a device-resident search that touches
+// no host memory at all: only the runtime's own copy path could have held that mapping).  A library cannot rule out what
+// else the process does with those pages, so by default pageable memory crosses through the library's pinned stages;
+// memory the caller pinned itself (hipHostMalloc / hipHostRegister / torch pin_memory) crosses directly.
+static bool host_register_allowed()
+{
+    static const bool allowed = [] {
+        const char *e = getenv("WS_HOST_REGISTER");
+        return e && atoi(e) == 1;
+    }();
+    return allowed;
+}
+
 void spans_attach(HostSpan *sp, int count, std::string *note, bool may_register = true)
 {
+    // Registering the caller's pageable memory is OFF unless asked for (WS_HOST_REGISTER=1): see host_register_allowed()
+    if (!host_register_allowed()) may_register = false;
     const uintptr_t ps = host_page();
     struct Hull { uintptr_t lo, hi; };
     std::vector<Hull> hulls;
@@ -246,25 +267,102 @@ void spans_attach(HostSpan *sp, int count, std::string *note, bool may_register 
     }
 }
 
-// The stages' host copies: a few threads for big buffers (one core moves ~14 GB/s, PCIe 50: a 9 MB image pair would
-// spend longer in memcpy than on the bus).
-void stage_copy(uint8_t *dst, const uint8_t *src, size_t n)
-{
-    const size_t kPiece = (size_t)1 << 20;
-    const unsigned want = (unsigned)std::min<size_t>(4, n / kPiece);
-    if (want < 2) { memcpy(dst, src, n); return; }
-    const size_t per = ((n / want) + 4095) & ~(size_t)4095;
-    std::thread helpers[3];
-    unsigned started = 0;
-    for (unsigned t = 1; t < want; ++t) {
-        const size_t off = t * per, len = off < n ? std::min(per, n - off) : 0;
-        if (!len) break;
-        try { helpers[started] = std::thread([=] { memcpy(dst + off, src + off, len); }); ++started; }
-        catch (...) { memcpy(dst + off, src + off, len); }
+// The stages' host copies: several threads for big buffers (one core moves ~12 GB/s, PCIe 50: a 9 MB image pair would
+// spend longer in memcpy than on the bus).  A small pool of helper threads, started at the first big copy and shared by
+// all contexts (one copy at a time uses it) -- a banded call copies a megabyte at a time, too little to start threads for
+// (tools/pool_stress.cpp runs this class under ThreadSanitizer).
+class CopyPool {
+public:
+    static CopyPool &get()
+    {
+        static CopyPool pool;
+        return pool;
     }
-    memcpy(dst, src, std::min(per, n));
-    for (unsigned t = 0; t < started; ++t) helpers[t].join();
-}
+    void copy(uint8_t *dst, const uint8_t *src, size_t n)
+    {
+        if (n < 2 * kPiece || workers_.empty()) { memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> one_at_a_time(submit_);
+        {
+            // (a helper that woke up late for the copy before is still inside work(): the job's fields are its to read)
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return active_ == 0; });
+            dst_ = dst; src_ = src; n_ = n;
+            pieces_ = (n + kPiece - 1) / kPiece;
+            next_.store(0);
+            done_ = 0;
+            ++generation_;
+        }
+        cv_.notify_all();
+        const size_t mine = work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_ += mine;
+        cv_done_.wait(lk, [&] { return done_ == pieces_ && active_ == 0; });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+
+private:
+    static constexpr size_t kPiece = (size_t)128 << 10;
+    CopyPool()
+    {
+        unsigned n = std::thread::hardware_concurrency();
+        n = n >= 16 ? 7 : n >= 8 ? 3 : n >= 4 ? 1 : 0; // helpers beside the calling thread
+        if (const char *e = getenv("WS_COPY_THREADS")) n = (unsigned)std::max(0, std::min(31, atoi(e) - 1));
+        for (unsigned i = 0; i < n; ++i) {
+            try { workers_.emplace_back([this] { loop(); }); }
+            catch (...) { break; }
+        }
+    }
+    size_t work()
+    {
+        size_t count = 0;
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= pieces_) break;
+            const size_t off = i * kPiece;
+            memcpy(dst_ + off, src_ + off, std::min(kPiece, n_ - off));
+            ++count;
+        }
+        return count;
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                ++active_;
+            }
+            const size_t count = work();
+            std::lock_guard<std::mutex> lk(m_);
+            done_ += count;
+            --active_;
+            cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex submit_, m_;
+    std::condition_variable cv_, cv_done_;
+    uint8_t *dst_ = nullptr;
+    const uint8_t *src_ = nullptr;
+    size_t n_ = 0, pieces_ = 0, done_ = 0;
+    int active_ = 0; // helpers inside work()
+    std::atomic<size_t> next_{0};
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+
+void stage_copy(uint8_t *dst, const uint8_t *src, size_t n) { CopyPool::get().copy(dst, src, n); }
 
 hipError_t stage_for(HostSpan &sp)
 {
@@ -284,12 +382,12 @@ hipError_t span_upload(HostSpan &sp, size_t off, void *dev, size_t bytes, hipStr
         sp.why = "the runtime refused a direct copy from caller-pinned memory";
     }
     if (sp.how != HostSpan::kStaged) return hipErrorInvalidValue;
-    if (!sp.loaded) {
-        const hipError_t e = stage_for(sp);
-        if (e != hipSuccess) return e;
-        stage_copy(sp.stage->p, sp.p, sp.n);
-        sp.loaded = true;
-    }
+    // just the bytes asked for, at their own offset in the stage (which is as long as the buffer): a call that uploads
+    // its images band by band copies the next band into the stage while the last one is on the bus
+    const hipError_t e = stage_for(sp);
+    if (e != hipSuccess) return e;
+    stage_copy(sp.stage->p + off, sp.p + off, bytes);
+    sp.loaded = true;
     return hipMemcpyAsync(dev, sp.stage->p + off, bytes, hipMemcpyHostToDevice, s);
 }
 
@@ -335,16 +433,21 @@ hipError_t span_download(HostSpan &sp, size_t off, size_t pitch, const void *dev
 
 // Hand staged downloads to the caller and release the registrations.  ONLY after every stream that carried a copy of
 // these spans is idle.  Returns false (and a note) if the runtime refused a release: a bug to be reported, not ignored.
-void span_scatter(HostSpan &sp) // (the copies into the stage are through: the caller of this has synchronised)
+void span_scatter_seg(HostSpan &sp, HostSpan::Seg &g) // (the copy of this segment into the stage is through)
 {
-    for (const HostSpan::Seg &g : sp.down) {
-        if (g.host_pitch == g.row_bytes || g.rows == 1) { // dense: one copy
-            stage_copy(sp.p + g.host_off, sp.stage->p + g.stage_off, g.row_bytes * g.rows);
-            continue;
-        }
+    if (!g.rows) return; // handed over already
+    if (g.host_pitch == g.row_bytes || g.rows == 1) { // dense: one copy
+        stage_copy(sp.p + g.host_off, sp.stage->p + g.stage_off, g.row_bytes * g.rows);
+    } else {
         for (size_t r = 0; r < g.rows; ++r)
             memcpy(sp.p + g.host_off + r * g.host_pitch, sp.stage->p + g.stage_off + r * g.row_bytes, g.row_bytes);
     }
+    g.rows = 0;
+}
+
+void span_scatter(HostSpan &sp) // (the copies into the stage are through: the caller of this has synchronised)
+{
+    for (HostSpan::Seg &g : sp.down) span_scatter_seg(sp, g);
     sp.down.clear();
 }
 
@@ -391,7 +494,7 @@ struct ws_context {
     hipStream_t copy_stream = nullptr; // host <-> device copies of the batched path, beside the searches
     hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
     static constexpr int kMaxBands = 8;
-    hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {};
+    hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {}, ev_band_down[kMaxBands] = {};
     unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up)
     DevBuf d_flag;                     // 256 bytes: word 0 = the integer box filter met a value it cannot carry
     int last_outliers_path = 0;        // ws_last_outliers_path
@@ -893,6 +996,7 @@ void ws_destroy(ws_context *ctx)
     for (int i = 0; i < ws_context::kMaxBands; ++i) {
         if (ctx->ev_band_up[i]) (void)hipEventDestroy(ctx->ev_band_up[i]);
         if (ctx->ev_band_done[i]) (void)hipEventDestroy(ctx->ev_band_done[i]);
+        if (ctx->ev_band_down[i]) (void)hipEventDestroy(ctx->ev_band_down[i]);
     }
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -965,6 +1069,7 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     for (int i = 0; i < nb; ++i) {
         if (!ctx->ev_band_up[i]) WS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_band_up[i], hipEventDisableTiming));
         if (!ctx->ev_band_done[i]) WS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_band_done[i], hipEventDisableTiming));
+        if (!ctx->ev_band_down[i]) WS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_band_down[i], hipEventDisableTiming));
     }
     const size_t span_l = (size_t)left->stride * (H - 1) + lb, span_r = (size_t)right->stride * (H - 1) + rb;
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
@@ -1017,6 +1122,15 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
         WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
         WS_HIP(ctx, span_download(sp[2], (size_t)ow * y0 * esz, (size_t)ow * esz, src, (size_t)ow * esz, (size_t)(y1 - y0), ctx->down_stream));
+        WS_HIP(ctx, hipEventRecord(ctx->ev_band_down[k], ctx->down_stream));
+    }
+    // a staged map: every band's rows go from the stage to the caller's buffer as soon as they are down, while the
+    // bands behind it are still being searched (segment k of the span is band k's download)
+    if (sp[2].how == HostSpan::kStaged && sp[2].down.size() == (size_t)nb) {
+        for (int k = 0; k < nb; ++k) {
+            WS_HIP(ctx, hipEventSynchronize(ctx->ev_band_down[k]));
+            span_scatter_seg(sp[2], sp[2].down[(size_t)k]);
+        }
     }
     return WS_OK;
     }();

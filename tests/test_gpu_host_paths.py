@@ -8,6 +8,7 @@ runs), shares them by reference count, leaves caller-pinned memory alone and sta
 ws_last_host_paths says which way the bytes went.  Results must be the oracle's, bit for bit, whichever way.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,15 @@ from stereo_reconstruction_amd.synthetic import make_pair
 pytestmark = pytest.mark.gpu
 
 BS, MAXD = 7, 40
+
+# Round 3, late: registering the caller's pageable memory is opt-in (WS_HOST_REGISTER=1; ws_capi.cpp,
+# host_register_allowed) -- by default such buffers cross through the library's pinned stages.  The tests below run
+# either way; the three that register heap pages THEMSELVES (a framework pinning part of a buffer) only run with the
+# library's registration on: that interplay is what they are about, and hipHostRegister on pages the allocator recycles is
+# what the default now keeps out of a process.
+REG = os.environ.get("WS_HOST_REGISTER") == "1"
+OURS = "registered" if REG else "staged"
+needs_registration = pytest.mark.skipif(not REG, reason="the library registers no caller memory unless WS_HOST_REGISTER=1")
 
 
 def own_pages(a):
@@ -53,12 +63,12 @@ def test_pageable_numpy_buffers_are_registered_for_the_call(wslib, gpu_ctx, orac
     want = oracle.block_left(left, right, BS, 0, MAXD)
     p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
     out = np.empty((120, 300))
-    assert host_call(wslib, gpu_ctx, p, left, right, out) == ("registered",) * 3
+    assert host_call(wslib, gpu_ctx, p, left, right, out) == (OURS,) * 3
     assert np.array_equal(out, want)
     # the same buffers again, and fresh ones at recycled addresses with other sizes
     for h in (120, 90, 120, 60):
         l2, r2, o2 = left[:h].copy(), right[:h].copy(), np.empty((h, 300))
-        assert host_call(wslib, gpu_ctx, p, l2, r2, o2) == ("registered",) * 3
+        assert host_call(wslib, gpu_ctx, p, l2, r2, o2) == (OURS,) * 3
         assert np.array_equal(o2, oracle.block_left(l2, r2, BS, 0, MAXD))
 
 
@@ -72,14 +82,14 @@ def test_left_and_right_cut_from_one_array_share_one_registration(wslib, gpu_ctx
     assert not L.flags["C_CONTIGUOUS"] and L.strides[0] == 2 * 260 * 3
     p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
     out = np.empty((100, 260), dtype=np.float32)
-    assert host_call(wslib, gpu_ctx, p, L, R, out) == ("registered",) * 3
+    assert host_call(wslib, gpu_ctx, p, L, R, out) == (OURS,) * 3
     assert np.array_equal(out.astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
     # output rows inside the same allocation as the images (a struct-of-frames buffer)
     blob = np.zeros(frame.nbytes + 100 * 260 * 4 + 64, dtype=np.uint8)
     blob[:frame.nbytes] = frame.reshape(-1)
     f2 = blob[:frame.nbytes].reshape(frame.shape)
     o2 = blob[frame.nbytes + 64 - (blob.ctypes.data + frame.nbytes) % 64:][:100 * 260 * 4].view(np.float32).reshape(100, 260)
-    assert host_call(wslib, gpu_ctx, p, f2[:, :260], f2[:, 260:], o2) == ("registered",) * 3
+    assert host_call(wslib, gpu_ctx, p, f2[:, :260], f2[:, 260:], o2) == (OURS,) * 3
     assert np.array_equal(o2.astype(np.float64), oracle.block_left(left, right, BS, 0, MAXD))
 
 
@@ -92,7 +102,7 @@ def test_tiny_buffers_on_one_page(wslib, gpu_ctx, oracle):
     out = slab[100 + 2 * left.nbytes + 64:]
     out = out[(-out.ctypes.data) % 8:][:12 * 24 * 8].view(np.float64).reshape(12, 24)
     p = wslib.make_params(wslib.VIEW_LEFT, 3, 0, 6, 1.0, "sad")
-    assert host_call(wslib, gpu_ctx, p, a, b, out) == ("registered",) * 3
+    assert host_call(wslib, gpu_ctx, p, a, b, out) == (OURS,) * 3
     assert np.array_equal(out, oracle.block_left(left, right, 3, 0, 6, cost="sad"))
 
 
@@ -112,6 +122,7 @@ def test_caller_pinned_memory_is_used_as_it_is(wslib, gpu_ctx, oracle):
     torch.cuda.synchronize()
 
 
+@needs_registration
 def test_a_range_the_caller_registered_in_part_goes_through_the_stage(wslib, gpu_ctx, oracle):
     import torch
     left, right, _ = make_pair(300, 120, MAXD, seed=305)
@@ -123,7 +134,7 @@ def test_a_range_the_caller_registered_in_part_goes_through_the_stage(wslib, gpu
         p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
         out = own_pages(np.empty((120, 300)))
         how = host_call(wslib, gpu_ctx, p, left, right, out)
-        assert how[0] == "staged" and how[1] == "registered" and how[2] == "registered", how
+        assert how[0] == "staged" and how[1] == OURS and how[2] == OURS, how
         assert np.array_equal(out, oracle.block_left(left, right, BS, 0, MAXD))
         # in bands too (the stage is filled once, the bands upload from it), and as the output buffer
         with wslib.WindowSearch(0) as ctx:
@@ -136,10 +147,10 @@ def test_a_range_the_caller_registered_in_part_goes_through_the_stage(wslib, gpu
                 p2 = wslib.make_params(wslib.VIEW_LEFT, BS, 0, 32)
                 ctx.set_host_bands(4)
                 how = host_call(wslib, ctx, p2, big_l, big_r, out2)
-                assert how == ("staged", "registered", "staged"), how
+                assert how == ("staged", OURS, "staged"), how
                 ctx.set_host_bands(0)
                 plain = own_pages(np.empty((1000, 1100)))
-                assert host_call(wslib, ctx, p2, big_l, big_r, plain) == ("staged", "registered", "registered")
+                assert host_call(wslib, ctx, p2, big_l, big_r, plain) == ("staged", OURS, OURS)
                 assert np.array_equal(out2, plain)
                 rows = (500, 540)
                 assert np.array_equal(plain[rows[0]:rows[1]], oracle.block_left(big_l, big_r, BS, 0, 32, rows=rows, threads=8)[rows[0]:rows[1]])
@@ -187,7 +198,7 @@ def test_crops_of_one_image_in_a_batch(wslib, gpu_ctx, oracle):
     assert np.array_equal(o_b.astype(np.float64), oracle.block_left(np.ascontiguousarray(Ls), Rs, BS, 0, MAXD))
     # single calls on the same buffers register them for the call, and only for the call
     out = np.empty((400, 320))
-    assert host_call(wslib, gpu_ctx, p, left, right, out) == ("registered",) * 3
+    assert host_call(wslib, gpu_ctx, p, left, right, out) == (OURS,) * 3
     assert np.array_equal(out, oracle.block_left(left, right, BS, 0, MAXD))
     # pinned by the caller: direct in a batch too
     import torch
@@ -209,8 +220,8 @@ def test_staged_maps_in_a_long_batch(wslib, gpu_ctx, oracle):
     p = wslib.make_params(wslib.VIEW_RIGHT, BS, 0, MAXD, 1.0, "sad")
     pairs = [make_pair(200, 90 + 8 * i, MAXD, seed=320 + i)[:2] for i in range(5)]
     outs = [np.full((l.shape[0], 256), -7.0) for l, _ in pairs]
-    for o in outs:
-        assert int(rt.cudaHostRegister(o.ctypes.data + 4096, 4096, 0)) == 0
+    for o in outs:   # (with the library's registration on: make the outputs unregistrable; off: they are staged anyway)
+        assert not REG or int(rt.cudaHostRegister(o.ctypes.data + 4096, 4096, 0)) == 0
     try:
         keep = []
         for (l, r), o in zip(pairs, outs):
@@ -221,7 +232,7 @@ def test_staged_maps_in_a_long_batch(wslib, gpu_ctx, oracle):
         assert gpu_ctx.last_host_paths()[2] == "staged"
     finally:
         for o in outs:
-            assert int(rt.cudaHostUnregister(o.ctypes.data + 4096)) == 0
+            assert not REG or int(rt.cudaHostUnregister(o.ctypes.data + 4096)) == 0
     for (l, r), o in zip(pairs, outs):
         assert np.array_equal(o[:, :200], oracle.block_right(l, r, BS, 0, MAXD, cost="sad")) and (o[:, 200:] == -7.0).all()
 
@@ -241,7 +252,7 @@ def test_an_error_in_the_middle_of_a_batch_leaves_nothing_behind(wslib, gpu_ctx,
     for o in gpu_ctx.search_many(p, [(left, right)] * 3, dtype=np.float64):
         assert np.array_equal(o, want)
     out = np.empty((120, 300))
-    assert host_call(wslib, gpu_ctx, p, left, right, out) == ("registered",) * 3 and np.array_equal(out, want)
+    assert host_call(wslib, gpu_ctx, p, left, right, out) == (OURS,) * 3 and np.array_equal(out, want)
 
 
 def test_consumers_take_pageable_and_partly_known_buffers(wslib, gpu_ctx):
@@ -251,7 +262,7 @@ def test_consumers_take_pageable_and_partly_known_buffers(wslib, gpu_ctx):
     want = gpu_ctx.convert_disparity_to_depth(disp, 700.0, 0.2)
     rt = torch.cuda.cudart()
     d2 = disp.copy()
-    assert int(rt.cudaHostRegister(d2.ctypes.data + 8192, 4096, 0)) == 0
+    assert not REG or int(rt.cudaHostRegister(d2.ctypes.data + 8192, 4096, 0)) == 0   # (a page the library cannot register)
     try:
         assert np.array_equal(gpu_ctx.convert_disparity_to_depth(d2, 700.0, 0.2), want)
         a = gpu_ctx.remove_disparity_outliers(disp, 9, 2.0, 3.0)
@@ -262,4 +273,4 @@ def test_consumers_take_pageable_and_partly_known_buffers(wslib, gpu_ctx):
         assert lib.ws_remove_disparity_outliers(gpu_ctx._h, padded.ctypes.data, 300, 200, 320, 9, 2.0, 3.0) == 0
         assert np.array_equal(padded[:, :300], a) and (padded[:, 300:] == 0).all()
     finally:
-        assert int(rt.cudaHostUnregister(d2.ctypes.data + 8192)) == 0
+        assert not REG or int(rt.cudaHostUnregister(d2.ctypes.data + 8192)) == 0
