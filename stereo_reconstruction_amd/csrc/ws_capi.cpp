@@ -275,8 +275,10 @@ class CopyPool {
 public:
     static CopyPool &get()
     {
-        static CopyPool pool;
-        return pool;
+        // (never destroyed: its threads wait on members of it, and a process that exits -- or a forked child, which has
+        // the object but not the threads -- must not join them)
+        static CopyPool *pool = new CopyPool;
+        return *pool;
     }
     void copy(uint8_t *dst, const uint8_t *src, size_t n)
     {
