@@ -54,7 +54,12 @@ constexpr int kMinXRuns = 4; // narrowest tile: 4 x-runs = 32 columns (D up to 1
 // pairs alternately, INTEGRATION.md -- share a CU.  The table behind march_nd's rule: profiles/r03/nd_grid.txt.
 static const MarchEntry kMarchWide[] = {WS_MARCH_TABLE(kND, "")};
 static const MarchEntry kMarchHalo[] = {WS_MARCH_HALO_ENTRY(7, 7), WS_MARCH_HALO_ENTRY(9, 9), WS_MARCH_HALO_ENTRY_COST(6, 6),
-                                       WS_MARCH_HALO_ENTRY_COST(8, 8)};
+                                       WS_MARCH_HALO_ENTRY_COST(8, 8),
+#if WS_FUSE
+                                       WS_MARCH_HALO_SSD_ENTRY(7, 7), WS_MARCH_HALO_SSD_ENTRY(9, 9),
+                                       WS_MARCH_HALO_SSD_ENTRY_COST(6, 6), WS_MARCH_HALO_SSD_ENTRY_COST(8, 8),
+#endif
+};
 
 // The thread shapes a search can run with: X columns x ND disparities per thread.
 struct MarchShape { int x, nd; };
@@ -148,9 +153,13 @@ static const MarchEntry *find_march_halo(const Canon &c)
         const char *e = getenv("WS_MARCH_HALO"); // development knob: 0 = never
         return e && atoi(e) == 0;
     }();
-    if (off || c.ssd || !same_shape(march_shape(c), kShapeWide)) return nullptr;
+    static const bool ssd_off = [] {
+        const char *e = getenv("WS_MARCH_HALO_SSD"); // development knob: 0 = not for SSD
+        return e && atoi(e) == 0;
+    }();
+    if (off || (c.ssd && ssd_off) || !same_shape(march_shape(c), kShapeWide)) return nullptr;
     for (const MarchEntry &e : kMarchHalo)
-        if (e.ww == c.ww && e.wh == c.wh) return &e;
+        if (e.ww == c.ww && e.wh == c.wh && e.ssd == c.ssd) return &e;
     return nullptr;
 }
 
@@ -322,7 +331,10 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
         // (6.19 against 7.52 instructions per hypothesis at 9 x 9, profiles/r03/isa_op_histogram.txt; a thread of the halo
         // kernels carries kNDHalo / nd times the hypotheses)
-        const double step = !p.halo ? 1.0 : (c.ww >= 9 ? 0.82 : c.ww == 8 ? 0.83 : c.ww == 7 ? 0.85 : 0.87) * kNDHalo / nd;
+        const double step = !p.halo ? 1.0
+                            : c.ssd ? (c.ww >= 8 ? 0.87 : 0.97) * pnd / nd // (measured: config 5, 9 x 9: -6.7 %; config 2, 7 x 7: 50 instead
+                                                                           // of 56 instructions per disparity and step, and no gain)
+                                    : (c.ww >= 9 ? 0.82 : c.ww == 8 ? 0.83 : c.ww == 7 ? 0.85 : 0.87) * pnd / nd;
         return p.passes * (1.0 + 0.02 * (p.passes - 1)) * step * strip_cost(p.strips, p.strip_rows);
     };
     m.halo = 0;
@@ -345,8 +357,9 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
             if (hch < min_chunks(sh)) continue;
             MarchLaunch h = m;
             h.halo = 1;
-            h.nd_per_thread = kNDHalo;
-            const int hch_total = ceil_div(dcount, kNDHalo);
+            const int hnd = find_march_halo(c)->nd; // 16 for the packed SAD kernels, 8 for the SSD ones
+            h.nd_per_thread = hnd;
+            const int hch_total = ceil_div(dcount, hnd);
             h.passes = ceil_div(hch_total, hch);
             h.nch = ceil_div(hch_total, h.passes);
             if (h.nch < min_chunks(sh)) h.nch = min_chunks(sh);

@@ -213,6 +213,59 @@ __device__ __forceinline__ void march_fused_ssd(int32_t (&V)[X][ND], int32_t (&b
     }
 }
 
+// lane + 1's value (DPP; march_pk_halo says why lane + 1 is the next run of the tile)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
+{
+    // row_shl:1: lane i reads lane i + 1 of its row of 16; the row's last lane reads 0 (bound_ctrl) -- it is a tile's
+    // last run.  (mov_dpp, not update_dpp(0, ...): that one costs a v_mov of the 0 in front of every move)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x101, 0xf, 0xf, true);
+}
+
+// The fused chain with the window's right-hand part taken from the neighbouring thread (see march_pk_halo below for the
+// idea and the tile geometry): chains over the thread's OWN X columns, window x = S[X-1] - S[x-1] of its own block plus
+// the next run's prefix N[x + WW - 1 - X] -- fetched by DPP inside the subtraction itself (v_subrev_u32_dpp).  Per
+// disparity at 7 x 7: 16 instead of 28 v_dot4, 14 instead of 8 subtractions.
+template <int X, int ND, int WW, bool CENTRED>
+__device__ __forceinline__ void march_fused_ssd_halo(int32_t (&V)[X][ND], int32_t (&best)[X], const uint32_t (&pa)[X],
+                                                     const uint32_t (&pb)[X + ND - 1], const uint32_t (&qa)[X],
+                                                     const uint32_t (&qb)[X + ND - 1], const uint32_t (&bi)[X + ND - 1], int shift)
+{
+    static_assert(WW - 1 <= X && WW >= 2, "the next run covers the whole overhang of a window");
+#pragma unroll
+    for (int j = 0; j < ND; j += 2) {
+        uint32_t S0[X], S1[X];
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < X; ++i) {
+            s0 = pix_dot<CENTRED>(pa[i], pb[i - j + ND - 1], s0);
+            s1 = pix_dot<CENTRED>(pa[i], pb[i - j + ND - 2], s1);
+            s0 = pix_dot<CENTRED>(qa[i], qb[i - j + ND - 1], s0);
+            s1 = pix_dot<CENTRED>(qa[i], qb[i - j + ND - 2], s1);
+            S0[i] = s0;
+            S1[i] = s1;
+        }
+#pragma unroll
+        for (int x = 0; x < X; ++x) {
+            constexpr int kLastInside = X - WW; // the last column whose window ends inside the thread's own columns
+            uint32_t w0, w1;                    // (V accumulates -2 * cross: minus the window's sum)
+            if (x <= kLastInside) {
+                const int hi = x <= kLastInside ? x + WW - 1 : 0;
+                w0 = (x ? S0[x - 1] : 0u) - S0[hi];
+                w1 = (x ? S1[x - 1] : 0u) - S1[hi];
+            } else {
+                const int m = x + WW - 1 - X; // the next run's prefix that completes this window
+                w0 = ((x ? S0[x - 1] : 0u) - S0[X - 1]) - from_next_lane(S0[m]);
+                w1 = ((x ? S1[x - 1] : 0u) - S1[X - 1]) - from_next_lane(S1[m]);
+            }
+            V[x][j] = (int32_t)((w0 << shift) + (uint32_t)V[x][j]);
+            V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
+            const int32_t k0 = (int32_t)bi[x - j + ND - 1] + V[x][j];
+            const int32_t k1 = (int32_t)bi[x - j + ND - 2] + V[x][j + 1];
+            best[x] = min(best[x], min(k0, k1));
+        }
+    }
+}
+
 // ---- SAD in packed 16-bit halves (windows up to 9 x 9) -----------------------------------------------------------
 // A window sum of absolute differences is at most ww * wh * 3 * 255: up to 9 x 9 it fits 16 bits, and then two
 // disparities share every register and every instruction behind the pixel differences themselves:
@@ -334,12 +387,6 @@ __device__ __forceinline__ void march_pk(uint32_t (&Vp)[X][ND / 2], uint32_t (&b
 // of a tile has no right-hand neighbour: its windows are wrong and never leave the workgroup -- tiles advance by
 // (nxr - 1) * X columns and the last run only feeds the one before it (it covers exactly that run's window overhang:
 // WW - 1 <= X).  A thread also reads only X pixels of A and X + ND - 1 of B per row instead of X + WW - 1 / X + WW + ND - 2.
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
-{
-    // row_shl:1: lane i reads lane i + 1 of its row of 16; the row's last lane reads 0 (bound_ctrl) -- it is a tile's
-    // last run.  (mov_dpp, not update_dpp(0, ...): that one costs a v_mov of the 0 in front of every move)
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x101, 0xf, 0xf, true);
-}
 
 template <int X, int ND, int WW, int PHASE, bool MASKED>
 __device__ __forceinline__ void march_pk_halo(uint32_t (&Vp)[X][ND / 2], uint32_t (&best)[X], const uint32_t (&pa)[X],
@@ -425,7 +472,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
     // (packed SAD: (cost << 16) | global tie tag as an UNSIGNED 32-bit key, cost field 0xffff = no valid candidate)
     constexpr bool PK = !SSD && march_pk_window(WW, WH);
-    static_assert(!HALO || PK, "the halo exchange is the packed SAD kernel's");
+    static_assert(!HALO || PK || (SSD && kFuseSsd), "the halo exchange: packed SAD, or the fused SSD chain");
     typedef typename std::conditional<SSD, long long, typename std::conditional<PK, uint32_t, int32_t>::type>::type slot_t;
     const slot_t kEmpty = SSD ? (slot_t)LLONG_MAX : PK ? (slot_t)0xffffffffu : (slot_t)INT_MAX;
 
@@ -435,7 +482,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int NT = blockDim.x, tid = threadIdx.x;
     const int tx = g.nxr * X, dt = g.nch * ND;
     // pixels of a row the tile's threads read (HALO: nobody reads past the last run's own columns)
-    const int n_a = HALO ? tx : tx + WW - 1, n_b = HALO ? tx + dt - 1 : tx + WW + dt - 2, n_bi = tx + dt - 1;
+    // (the SSD halo kernel keeps the long chains while a strip's window fills: it reads what the plain kernel reads)
+    const int n_a = HALO && PK ? tx : tx + WW - 1, n_b = HALO && PK ? tx + dt - 1 : tx + WW + dt - 2, n_bi = tx + dt - 1;
     const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
     const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
     const int a_w = NREG * ro_a, b_w = NREGB * ro_b, bi_w = NREGB * ro_bi;
@@ -649,6 +697,16 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     march_row<X, ND, WW, SSD, CENTRED, +1, false>(V, best, addA, ro_a, addB, ro_b, nullptr, 0, shift);
                 } else if constexpr (PHASE == 1) {
                     march_row<X, ND, WW, SSD, CENTRED, +1, true>(V, best, addA, ro_a, addB, ro_b, brow, ro_bi, shift);
+                } else if constexpr (SSD && kFuseSsd && HALO) { // ... over the thread's own columns, the rest from lane + 1
+                    uint32_t pa[X], pb[X + ND - 1], qa[X], qb[X + ND - 1], bi[X + ND - 1];
+                    lds_run<X, NREG>(pa, addA, ro_a);
+                    lds_run<X + ND - 1, NREGB>(pb, addB, ro_b);
+                    lds_run<X + ND - 1, NREGB>(bi, reinterpret_cast<const uint32_t *>(brow), ro_bi);
+                    lds_run<X, NREG>(qa, subA, ro_a);
+                    lds_run<X + ND - 1, NREGB>(qb, subB, ro_b);
+#pragma unroll
+                    for (int i = 0; i < X; ++i) qa[i] = ~qa[i];
+                    march_fused_ssd_halo<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
                 } else if constexpr (SSD && kFuseSsd) { // row a enters and row a - WH leaves in one chain
                     uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2], bi[X + ND - 1];
                     march_load<X, ND, WW, true, true>(pa, pb, bi, addA, ro_a, addB, ro_b, brow, ro_bi);
@@ -750,6 +808,12 @@ const MarchEntry *march_table_narrow(int *count);
 // that wide took several d-group passes, each a round trip of the key plane), windows 7 .. 9 wide (left view) and
 // 6 .. 8 (right view, with the cost-writing twin); narrower windows have little overhang to save
 constexpr int kNDHalo = 16;
+// ... and of the fused SSD chain (march_fused_ssd_halo), 8 disparities per thread like the plain kernel
+#define WS_MARCH_HALO_SSD_ENTRY(W, H)                                                                                \
+    {kX, W, H, 1, kND, ws_march_kernel<kX, kND, W, H, true, kMaxT, false, true>, nullptr, "ws_march_kernel<ssd," #W "x" #H ",halo>"}
+#define WS_MARCH_HALO_SSD_ENTRY_COST(W, H)                                                                           \
+    {kX, W, H, 1, kND, ws_march_kernel<kX, kND, W, H, true, kMaxT, false, true>,                                     \
+     ws_march_kernel<kX, kND, W, H, true, kMaxT, true, true>, "ws_march_kernel<ssd," #W "x" #H ",halo>"}
 #define WS_MARCH_HALO_ENTRY(W, H)                                                                                    \
     {kX, W, H, 0, kNDHalo, ws_march_kernel<kX, kNDHalo, W, H, false, kMaxT, false, true>, nullptr,                   \
      "ws_march_kernel<sad," #W "x" #H ",halo>"}

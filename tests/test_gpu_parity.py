@@ -99,12 +99,42 @@ def test_halo_exchange_sad_kernels(wslib, gpu_ctx, oracle, view, bs):
             band = fn(left, right, bs, dmin, dmax, cost="sad", rows=(y0, y0 + 2), threads=8)
             assert np.array_equal(got[y0:y0 + 2], band[y0:y0 + 2]), (w, h, dmin, dmax, levels, y0)
     assert used >= 3, used
-    # the other cost and the narrow windows keep the plain kernels
+    # the narrow windows keep the plain kernels
     left, right, _ = make_pair(2000, 600, 200, seed=3)
-    on_device(left, right, bs, 0, 512, "ssd")
-    assert "halo" not in gpu_ctx.last_launch()["kernel"]
     on_device(left, right, 5, 0, 512, "sad")
     assert "halo" not in gpu_ctx.last_launch()["kernel"]
+
+
+@pytest.mark.parametrize("view", ["left", "right"])
+def test_halo_exchange_ssd_kernels(wslib, gpu_ctx, oracle, view):
+    """The fused SSD chain with the same exchange (march_fused_ssd_halo; the planner takes it for the 8 / 9 wide windows of
+    large searches -- config 5's own test runs that plan): against oracle row bands over the full width, and -- whole maps --
+    against the plain kernel; a caller's tile width of 16 or 8 runs selects the halo kernel, any other the plain one."""
+    import torch
+    vw = wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT
+    for (w, h, bs, dmin, dmax, runs) in ((2400, 700, 9, 0, 512, 16), (3000, 500, 9, 7, 1031, 16), (1500, 400, 7, 0, 256, 16),
+                                         (1700, 300, 7, 0, 300, 8)):
+        left, right, _ = make_pair(w, h, min(dmax, w // 3), seed=w + bs)
+        left[h // 2, w // 3] = 0
+        p = wslib.make_params(vw, bs, dmin, dmax, 1.0, "ssd")
+        tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        maps = []
+        try:
+            for x_runs in (runs, 12):                         # 12 runs per tile: never the halo kernel
+                gpu_ctx.set_tuning(x_runs_per_tile=x_runs)
+                to = torch.empty((h, w), dtype=torch.float32, device="cuda")
+                gpu_ctx.search_device(p, tl, tr, to, None)
+                torch.cuda.synchronize()
+                maps.append((to.cpu().numpy().astype(np.float64), gpu_ctx.last_launch()["kernel"]))
+        finally:
+            gpu_ctx.set_tuning()
+        assert "halo" in maps[0][1] and "halo" not in maps[1][1], (w, h, bs, maps[0][1], maps[1][1])
+        assert np.array_equal(maps[0][0], maps[1][0]), (w, h, bs, dmin, dmax)
+        half = (bs - 1) // 2
+        fn = oracle.block_left if view == "left" else oracle.block_right
+        for y0 in (half, h // 2):
+            band = fn(left, right, bs, dmin, dmax, cost="ssd", rows=(y0, y0 + 2), threads=8)
+            assert np.array_equal(maps[0][0][y0:y0 + 2], band[y0:y0 + 2]), (w, h, bs, y0)
 
 
 def test_halo_and_plain_sad_kernels_agree_on_random_large_pairs(wslib, gpu_ctx):
