@@ -332,8 +332,8 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         // (6.19 against 7.52 instructions per hypothesis at 9 x 9, profiles/r03/isa_op_histogram.txt; a thread of the halo
         // kernels carries kNDHalo / nd times the hypotheses)
         const double step = !p.halo ? 1.0
-                            : c.ssd ? (c.ww >= 8 ? 0.87 : 0.97) * pnd / nd // (measured: config 5, 9 x 9: -6.7 %; config 2, 7 x 7: 50 instead
-                                                                           // of 56 instructions per disparity and step, and no gain)
+                            : c.ssd ? (c.ww >= 8 ? 0.87 : 0.93) * pnd / nd // (measured: config 5, 9 x 9: -6.7 %; config 2, 7 x 7: 50 instead of 56
+                                                                           // instructions per disparity and step, 0.1205 vs 0.1208 ms with 59- instead of 54-row strips)
                                     : (c.ww >= 9 ? 0.82 : c.ww == 8 ? 0.83 : c.ww == 7 ? 0.85 : 0.87) * pnd / nd;
         return p.passes * (1.0 + 0.02 * (p.passes - 1)) * step * strip_cost(p.strips, p.strip_rows);
     };
