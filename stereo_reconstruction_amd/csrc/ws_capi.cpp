@@ -497,7 +497,7 @@ struct ws_context {
     hipStream_t down_stream = nullptr; // ws_search_host in bands: maps go down here while images still come up on copy_stream
     static constexpr int kMaxBands = 8;
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {}, ev_band_down[kMaxBands] = {};
-    unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up)
+    unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up; word 1: the integer box filter met a value it cannot carry)
     DevBuf d_flag;                     // 256 bytes: word 0 = the integer box filter met a value it cannot carry
     int last_outliers_path = 0;        // ws_last_outliers_path
     int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
