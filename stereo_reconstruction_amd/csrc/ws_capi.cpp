@@ -499,6 +499,10 @@ struct ws_context {
     hipEvent_t ev_band_up[kMaxBands] = {}, ev_band_done[kMaxBands] = {}, ev_band_down[kMaxBands] = {};
     unsigned int *status_host = nullptr, *status_dev = nullptr; // mapped pinned words the kernels flag trouble in (word 0: ws_smooth_left_bands_kernel gave up; word 1: the integer box filter met a value it cannot carry)
     DevBuf d_flag;                     // 256 bytes: word 0 = the integer box filter met a value it cannot carry
+    bool plan_valid = false, plan_ok = false; // run_search: the last problem's plan
+    Canon plan_canon{};
+    int plan_tune[3] = {0, 0, 0};
+    MarchLaunch plan_launch{};
     int last_outliers_path = 0;        // ws_last_outliers_path
     int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
     std::vector<HostSpan> batch_spans; // caller buffers of the pairs enqueued since the last ws_wait (released there)
@@ -790,8 +794,23 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     Canon c{};
     MarchLaunch m{};
     Plane ring_a{}, ring_b{}, ring_bi{};
-    bool march = make_canon(p, L, R, &c) &&
-                 march_plan(c, ctx->num_cus, ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads, &m);
+    // (the plan of the last problem is kept: a queue of equal pairs asks for the same one every call, and the planner
+    // walks every strip count for up to three candidate tilings and two workgroup sizes -- 5 us of a 15 us enqueue)
+    bool march = make_canon(p, L, R, &c);
+    if (march) {
+        const int tune[3] = {ctx->tune_nxr, ctx->tune_rows, ctx->tune_threads};
+        if (ctx->plan_valid && !memcmp(&ctx->plan_canon, &c, sizeof c) && !memcmp(ctx->plan_tune, tune, sizeof tune)) {
+            m = ctx->plan_launch;
+            march = ctx->plan_ok;
+        } else {
+            march = march_plan(c, ctx->num_cus, tune[0], tune[1], tune[2], &m);
+            ctx->plan_canon = c;
+            memcpy(ctx->plan_tune, tune, sizeof tune);
+            ctx->plan_launch = m;
+            ctx->plan_ok = march;
+            ctx->plan_valid = true;
+        }
+    }
     if (march) {
         Plane pa{}, pb{}, pbi{};
         march_plane_geometry(c, m, &pa, &pb, &pbi);
