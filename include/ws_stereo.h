@@ -124,10 +124,10 @@ int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int
  * as called from ImageRectifier::computeDisparityMapLeft/Right (rectification.cpp:66-88)
  * and rectification_main.cpp:194-195.
  * out: h1 x w1 (LEFT) or h2 x w2 (RIGHT, LINEAR) elements of out_dtype, out_stride in
- * elements.  Copies in, runs, copies out, returns when the map is complete.  The three buffers are
- * registered with the HIP runtime (hipHostRegister) for the duration of the call and released before it
- * returns -- every entry point taking host buffers does that; a buffer the caller has registered itself
- * is used as it is.
+ * elements.  Copies in, runs, copies out, returns when the map is complete.  Pageable buffers cross
+ * through pinned staging memory of the library's (with WS_HOST_REGISTER=1 in the environment they are
+ * registered with the HIP runtime for the duration of the call instead) -- every entry point taking host
+ * buffers does that; a buffer the caller has pinned itself is used as it is.
  */
 int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left,
                    const ws_image *right, void *out, int out_stride, int out_dtype);
@@ -227,7 +227,8 @@ int ws_set_host_bands(ws_context *ctx, int bands);
 int ws_device_status(ws_context *ctx, void *stream);
 /*
  * How the bytes of the last host call's three buffers (left, right, out; for a batch: of its last pair) crossed:
- * 0 = not a linear span (gathered rows), 1 = registered by this library for the duration of the call, 2 = memory the
+ * 0 = not a linear span (gathered rows), 1 = registered by this library for the duration of the call (only with
+ * WS_HOST_REGISTER=1), 2 = memory the
  * caller (or a framework) had pinned already, used as it is, 3 = through pinned staging memory of the library
  * (INTEGRATION.md section 2 says when).  Stands in for nothing in the reference (cv::Mat buffers are pageable and
  * rectification.cpp:66-88 never leaves the host); for tests and reports.
