@@ -31,3 +31,22 @@ def test_teddy_quarter_bad2_is_plausible(oracle):
     assert res["n"] > 100000
     assert res["invalid"] < 5.0
     assert 5.0 < res["bad"] < 60.0      # a 5x5 WTA block matcher: far from good, far from random
+
+
+def test_reference_held_disparity_image_is_plausible(oracle):
+    """The ONE disparity image the reference's tree holds, results/PerceptualWindowSearch/test_result.png (Teddy-H, values
+    0 .. 199 = the pipeline's computeDisparityMapRight(17, 0, 200, .), main.cpp:40), against the oracle on the same
+    pixels.  A plausibility anchor, NOT a pin: the stored image comes from a related revision (a centred 17 x 17 window
+    and an 8-pixel zero ring; BlockSearch.cpp:88-179 as it stands has a 16 x 16 window covering [x-8, x+8) and no ring),
+    so equality is not expected -- but it is the only expectation in this suite that the builder did not compute
+    (fixture: tools/make_anchor_fixture.py; the review measured 0.94 over columns 8 .. 690 of the whole image)."""
+    g = load_golden("teddyH_reference_disparity_crop")
+    h = int(g["halo"])
+    out = oracle.block_right(g["left"], g["right"], int(g["block_size"]), int(g["min_disparity"]), int(g["max_disparity"]), threads=4)
+    stored = g["stored"].astype(np.float64)
+    inner = (slice(h, out.shape[0] - h), slice(h, out.shape[1] - h))  # complete windows, complete candidate ranges
+    assert (out[inner] == stored[inner]).mean() >= 0.90
+    assert (np.abs(out[inner] - stored[inner]) <= 1).mean() >= 0.97
+    # the left view is not what the image holds: the anchor does discriminate
+    left_view = oracle.block_left(g["left"][:, :out.shape[1]], g["right"], 17, 0, 200, threads=4)
+    assert (left_view[inner] == stored[inner]).mean() < 0.5
