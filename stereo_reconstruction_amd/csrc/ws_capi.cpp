@@ -490,7 +490,7 @@ struct ws_context {
     hipStream_t scratch_stream = nullptr; // ... the stream it ran on
     bool scratch_busy = false;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, bias, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
     Job jobs[2];             // ws_enqueue_host alternates between two slots
     int job_next = 0;
     hipStream_t copy_stream = nullptr; // host <-> device copies of the batched path, beside the searches
@@ -519,6 +519,8 @@ struct ws_context {
     Plane last_pa{}, last_pb{};
     int last_skip[4] = {0, 0, 0, 0};
     bool want_cost = false;       // run_search: also leave the winners' costs (right view, smoothFactor)
+    bool want_planes = false;     // run_search: also pack the dword planes (the left view's smoothFactor pass reads them)
+    bool last_planes = false;     // ... and whether the last search did
     int32_t *last_cost = nullptr; // where it left them (pitch = plane width), or null
     double *direct_f64 = nullptr; // run_search: the kernels store the map as doubles here (CV_64F out without a widening pass)
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
@@ -701,7 +703,9 @@ int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const 
     if (q.view == WS_VIEW_LEFT && q.smooth_factor != 1.0) {
         // the data-parallel search (smoothFactor 1) gives d1; the raster-order pass does the rest
         q.smooth_factor = 1.0;
+        ctx->want_planes = true;
         int rc = run_search(ctx, &q, L, R, out, out_stride, s);
+        ctx->want_planes = false;
         if (rc != WS_OK) return rc;
         GenericArgs ga{};
         ga.L = L->data; ga.R = R->data;
@@ -713,7 +717,7 @@ int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const 
         // per pixel the best candidate's cost (0 <= s <= 1) or the three best candidates
         if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
         uint32_t *top3 = static_cast<uint32_t *>(ctx->top3.p);
-        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march ? &ctx->last_canon : nullptr,
+        WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march && ctx->last_planes ? &ctx->last_canon : nullptr,
                                        ctx->last_pa, ctx->last_pb, ctx->status_dev, s));
         return WS_OK;
     }
@@ -740,7 +744,7 @@ int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const 
         ga.bs_pitch = (R->width + 63) & ~63;
     }
     if ((rc = ensure(ctx, ctx->sel_planes, smooth_planes_bytes(R->width, R->height))) != WS_OK) return rc;
-    const bool on_planes = p->view == WS_VIEW_RIGHT && !p->var_block && ctx->last_march && ctx->last_cost;
+    const bool on_planes = p->view == WS_VIEW_RIGHT && !p->var_block && ctx->last_march && ctx->last_planes && ctx->last_cost;
     if (on_planes) {
         ga.skip_x0 = ctx->last_skip[0]; ga.skip_x1 = ctx->last_skip[1];
         ga.skip_y0 = ctx->last_skip[2]; ga.skip_y1 = ctx->last_skip[3];
@@ -793,7 +797,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     }
     Canon c{};
     MarchLaunch m{};
-    Plane ring_a{}, ring_b{}, ring_bi{};
+    Plane ring_a{}, ring_b{};
     // (the plan of the last problem is kept: a queue of equal pairs asks for the same one every call, and the planner
     // walks every strip count for up to three candidate tilings and two workgroup sizes -- 5 us of a 15 us enqueue)
     bool march = make_canon(p, L, R, &c);
@@ -811,19 +815,12 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
             ctx->plan_valid = true;
         }
     }
+    // Dword planes of both images: only for the kernels BESIDE the marching kernel that still read them -- the right
+    // view's border ring, the sub-pixel refine, the smoothFactor passes.  The marching kernel reads the caller's bytes.
+    const bool planes = march && (p->view == WS_VIEW_RIGHT || p->subpixel || ctx->want_planes);
     if (march) {
-        Plane pa{}, pb{}, pbi{};
-        march_plane_geometry(c, m, &pa, &pb, &pbi);
+        Plane pa{}, pb{};
         int rc;
-        if ((rc = ensure(ctx, ctx->plane_a, (size_t)pa.pitch * c.ha * 4)) != WS_OK) return rc;
-        if ((rc = ensure(ctx, ctx->plane_b, (size_t)pb.pitch * c.hb * 4)) != WS_OK) return rc;
-        if (c.ssd && (rc = ensure(ctx, ctx->bias, (size_t)pbi.pitch * c.ha * 4)) != WS_OK) return rc;
-        pa.data = static_cast<uint32_t *>(ctx->plane_a.p);
-        pb.data = static_cast<uint32_t *>(ctx->plane_b.p);
-        pbi.data = static_cast<uint32_t *>(ctx->bias.p);
-        ring_a = pa;
-        ring_b = pb;
-        ring_bi = pbi;
         const ws_image *ia = p->view == WS_VIEW_LEFT ? L : R;
         const ws_image *ib = p->view == WS_VIEW_LEFT ? R : L;
         if (c.mirror) {
@@ -832,10 +829,16 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
             ga.skip_x0 = c.ox0; ga.skip_x1 = c.ox1;
         }
         ga.skip_y0 = c.oy0; ga.skip_y1 = c.oy1;
-        // left view: the pixels outside the interior only need the images, they ride along here;
-        // the right view's ring runs on the packed planes after the marching kernel
-        WS_HIP(ctx, launch_prepare(c, m, ia->data, ia->stride, pa, ib->data, ib->stride, pb, pbi,
-                                   p->view == WS_VIEW_LEFT ? &ga : nullptr, s));
+        if (planes) {
+            march_plane_geometry(c, m, &pa, &pb);
+            if ((rc = ensure(ctx, ctx->plane_a, (size_t)pa.pitch * c.ha * 4)) != WS_OK) return rc;
+            if ((rc = ensure(ctx, ctx->plane_b, (size_t)pb.pitch * c.hb * 4)) != WS_OK) return rc;
+            pa.data = static_cast<uint32_t *>(ctx->plane_a.p);
+            pb.data = static_cast<uint32_t *>(ctx->plane_b.p);
+            ring_a = pa;
+            ring_b = pb;
+            WS_HIP(ctx, launch_pack(c, ia->data, ia->stride, pa, ib->data, ib->stride, pb, s));
+        }
         if (ctx->profiling) WS_HIP(ctx, hipEventRecord(ctx->evk0, s));
         const int keys_pitch = (c.wa + 15) & ~15;
         if (m.passes > 1 && (rc = ensure(ctx, ctx->keys, (size_t)keys_pitch * c.ha * 8)) != WS_OK) return rc;
@@ -845,7 +848,10 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
             cost_out = static_cast<int32_t *>(ctx->cost.p);
         }
         ctx->last_cost = cost_out;
-        WS_HIP(ctx, launch_march(c, m, pa, pb, pbi, out, ctx->direct_f64, out_stride, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
+        // left view: the marching kernel also writes the zeros outside its interior (BlockSearch.cpp:33,36,38); the
+        // right view's ring runs on the packed planes after it
+        WS_HIP(ctx, launch_march(c, m, ia->data, ia->stride, ib->data, ib->stride, out, ctx->direct_f64, out_stride,
+                                 p->view == WS_VIEW_LEFT, L->width, L->height, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
             ctx->kernel_timed = true;
@@ -868,6 +874,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     else if (!march)
         WS_HIP(ctx, launch_generic(ga, s));
     ctx->last_march = march;
+    ctx->last_planes = planes;
     if (march) {
         ctx->last_canon = c; ctx->last_pa = ring_a; ctx->last_pb = ring_b;
         ctx->last_skip[0] = ga.skip_x0; ctx->last_skip[1] = ga.skip_x1;
@@ -996,7 +1003,7 @@ void ws_destroy(ws_context *ctx)
         (void)spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), nullptr);
         ctx->batch_spans.clear();
     }
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->bias, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64, &ctx->d_flag})
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64, &ctx->d_flag})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->h_out, &ctx->h_aux[0], &ctx->h_aux[1], &ctx->jobs[0].h_left, &ctx->jobs[0].h_right,

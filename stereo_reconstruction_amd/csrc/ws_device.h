@@ -27,6 +27,43 @@ __host__ __device__ constexpr int march_region_dwords(int n, int nreg)
     return 4 * ((((n + 3) >> 2) + nreg - 1) / nreg + 1);
 }
 
+// bytes a raw row buffer needs (ws_march_kernel.h, raw_dma): up to 15 of alignment in front, 3 per pixel, a dword of
+// over-read behind; in dwords, a multiple of 4
+__host__ __device__ constexpr int march_raw_dwords(int n4) { return ((16 + 3 * n4 + 16 + 15) >> 4) << 2; }
+
+// The marching kernel's LDS, as the kernel lays it out and the planner prices it (one definition for both):
+// ring A | ring B | 2 bias rows (SSD) | 2 rows of merge slots | 2 raw rows of each image | 2 rows of column sums (SSD)
+struct MarchLds {
+    int n_a, n_b, n_bi;   // pixels of a row the tile's threads read: reference image, target image, bias values
+    int n_a4, n_b4;       // ... rounded up to quads (what is unpacked)
+    int a_w, b_w, bi_w;   // dwords per ring row (region layout)
+    int rawa_dw, rawb_dw; // dwords per raw row buffer
+    int g_dw;             // dwords per row of column sums
+    int nr;               // ring rows
+    int bytes;
+};
+__host__ __device__ inline MarchLds march_lds_layout(int x, int nd, int ww, int wh, bool ssd, bool short_runs, int nxr, int nch)
+{
+    MarchLds l{};
+    const int tx = nxr * x, dt = nch * nd;
+    const int nreg = x / 4, nregb = march_nreg_b(x, nd);
+    // (short_runs: the packed SAD halo-exchange kernels, whose threads read their own columns only)
+    l.n_a = short_runs ? tx : tx + ww - 1;
+    l.n_b = short_runs ? tx + dt - 1 : tx + ww + dt - 2;
+    l.n_bi = tx + dt - 1;
+    l.n_a4 = (l.n_a + 3) & ~3;
+    l.n_b4 = (l.n_b + 3) & ~3;
+    l.a_w = nreg * march_region_dwords(l.n_a, nreg);
+    l.b_w = nregb * march_region_dwords(l.n_b, nregb);
+    l.bi_w = ssd ? nregb * march_region_dwords(l.n_bi, nregb) : 0;
+    l.rawa_dw = march_raw_dwords(l.n_a4);
+    l.rawb_dw = march_raw_dwords(l.n_b4);
+    l.g_dw = ssd ? l.n_b4 + 16 : 0;
+    l.nr = wh + 3;
+    l.bytes = 4 * (l.nr * (l.a_w + l.b_w) + 2 * l.bi_w + 2 * (l.rawa_dw + l.rawb_dw) + 2 * l.g_dw) + 2 * tx * (ssd ? 8 : 4);
+    return l;
+}
+
 __device__ __forceinline__ uint32_t pix_sad(uint32_t a, uint32_t b, uint32_t acc)
 {
     return __builtin_amdgcn_sad_u8(a, b, acc); // v_sad_u8: acc + sum |a.b[i] - b.b[i]|

@@ -54,24 +54,22 @@ struct MarchLaunch {
 bool march_supported(const Canon &c);
 // 1 if this SSD window needs centred (byte - 128) planes to keep its sums in 32 bits
 int march_centred(const Canon &c);
-// does the SSD marching kernel take the entering and the leaving row in one chain (the bias plane then carries the
-// correction term of the complemented leaving rows, per strip)
-bool march_fused(const Canon &c);
 // Fill the tiling for this problem (tuning values of 0 = automatic).
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out);
 // Plane geometry (pad / pitch) the plan needs.
-void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias);
+void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b);
 
 struct GenericArgs;
-// pack both planes, sum the bias rows (SSD) and -- when `generic` is given (left view) -- write the
-// pixels outside the marching interior, all in one launch of independent workgroups
-hipError_t launch_prepare(const Canon &c, const MarchLaunch &m, const uint8_t *src_a, int stride_a, Plane dst_a,
-                          const uint8_t *src_b, int stride_b, Plane dst_b, Plane bias, const GenericArgs *generic,
-                          hipStream_t s);
-// keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
-hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, double *out64, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
+// pack both planes (for the kernels beside the marching kernel that read planes: border ring, refine, smoothFactor passes)
+hipError_t launch_pack(const Canon &c, const uint8_t *src_a, int stride_a, Plane dst_a, const uint8_t *src_b, int stride_b,
+                       Plane dst_b, hipStream_t s);
+// The hot kernel, on the caller's CV_8UC3 rows themselves (no planes, no pre-pass): img_a carries the outputs (left view:
+// the left image), img_b the candidates.  border: also write the zeros of the out_w x out_h map outside the marching
+// interior (left view).  keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
+hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img_a, int stride_a, const uint8_t *img_b, int stride_b,
+                        float *out, double *out64, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
+                        int32_t *cost_out, int cost_pitch,
                         hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2); out64: see GenericArgs
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 bool march_has_cost(const Canon &c); // is there an instantiation that also writes cost_out?

@@ -178,8 +178,6 @@ bool march_has_cost(const Canon &c)
 
 int march_centred(const Canon &c) { return c.ssd && ssd_needs_centring(c.ww, c.wh, march_nd(c)); }
 
-bool march_fused(const Canon &c) { return c.ssd && kFuseSsd; }
-
 bool march_supported(const Canon &c)
 {
     if (!find_march(c)) return false;
@@ -318,14 +316,7 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         }
         p.strip_rows = ceil_div(out_h, strips);
         p.strips = ceil_div(out_h, p.strip_rows);
-        const int dt = p.nch * pnd;
-        const int nreg = X / 4, nregb = march_nreg_b(X, pnd);
-        const int a_w = nreg * march_region_dwords(tx + c.ww - 1, nreg),
-                  b_w = nregb * march_region_dwords(tx + c.ww + dt - 2, nregb),
-                  bi_w = nregb * march_region_dwords(tx + dt - 1, nregb);
-        const int nr = c.wh + 2;
-        p.lds_bytes = c.ssd ? (size_t)(nr * a_w + nr * b_w + 2 * bi_w) * 4 + (size_t)2 * tx * 8
-                            : (size_t)(nr * a_w + nr * b_w) * 4 + (size_t)2 * tx * 4;
+        p.lds_bytes = (size_t)march_lds_layout(X, pnd, c.ww, c.wh, c.ssd != 0, p.halo && !c.ssd && march_pk_window(c.ww, c.wh), runs, p.nch).bytes;
         if (p.lds_bytes > 160 * 1024) return 0.0;
         // a row step of the halo-exchange kernel against the plain one's, from the instruction counts (march_pk_halo);
         // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
@@ -386,22 +377,19 @@ static int aligned_pad(int base)
     return pad;
 }
 
-void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b, Plane *bias)
+void march_plane_geometry(const Canon &c, const MarchLaunch &m, Plane *a, Plane *b)
 {
     const int tx = m.nxr * m.x_per_thread, dt = m.nch * m.nd_per_thread;
     const int dhi_t = c.d_lo + m.passes * dt - 1; // the last pass reaches furthest to the left
-    const int n_a = tx + c.ww - 1, n_b = tx + c.ww + m.passes * dt - 2, n_bi = tx + m.passes * dt - 1;
+    const int n_a = tx + c.ww - 1, n_b = tx + c.ww + m.passes * dt - 2;
     // first column each tile row copy starts at (tile 0); tiles advance by tile_cols (a multiple of 8)
     const int base_a = c.ox0 + c.wx0;
     const int base_b = c.ox0 + c.wx0 + c.boff - dhi_t;
-    const int base_bi = c.ox0 + c.boff - dhi_t;
     const int last = (m.tiles - 1) * m.tile_cols;
     a->pad = aligned_pad(base_a);
     a->pitch = round_up(std::max(base_a + last + round_up(n_a, 4), c.wa) + a->pad + 4, 64);
     b->pad = aligned_pad(base_b);
     b->pitch = round_up(std::max(base_b + last + round_up(n_b, 4), c.wb) + b->pad + 4, 64);
-    bias->pad = aligned_pad(base_bi);
-    bias->pitch = round_up(base_bi + last + round_up(n_bi, 4) + bias->pad + 4, 64);
 }
 
 
@@ -411,36 +399,35 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &m)
     return e ? e->name : "";
 }
 
-hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, Plane bias,
-                        float *out, double *out64, int out_pitch, void *keys, int keys_pitch, int32_t *cost_out, int cost_pitch,
-                        hipStream_t s)
+hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img_a, int stride_a, const uint8_t *img_b, int stride_b,
+                        float *out, double *out64, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
+                        int32_t *cost_out, int cost_pitch, hipStream_t s)
 {
     const MarchEntry *e = m.halo ? find_march_halo(c) : find_march(c);
     if (!e) return hipErrorInvalidValue;
     MarchArgs g{};
-    g.A = a.data;
-    g.B = b.data;
-    g.bias = reinterpret_cast<const int32_t *>(bias.data);
-    g.pitch_bi = bias.pitch;
-    g.pad_bi = bias.pad;
+    g.st.img_a = img_a;
+    g.st.stride_a = stride_a;
+    g.st.img_b = img_b;
+    g.st.stride_b = stride_b;
+    g.st.wb = c.wb;
     g.out = out;
     g.out64 = out64;
-    g.pitch_a = a.pitch;
-    g.pad_a = a.pad;
-    g.pitch_b = b.pitch;
-    g.pad_b = b.pad;
     g.out_pitch = out_pitch;
-    g.wa = c.wa;
-    g.nxr = m.nxr;
-    g.nch = m.nch;
-    g.wx0 = c.wx0;
+    g.border = border;
+    g.out_w = out_w;
+    g.out_h = out_h;
+    g.st.wa = c.wa;
+    g.st.nxr = m.nxr;
+    g.st.nch = m.nch;
+    g.st.wx0 = c.wx0;
     g.wy0 = c.wy0;
-    g.boff = c.boff;
+    g.st.boff = c.boff;
     g.d_lo = c.d_lo;
     g.d_hi = c.d_hi;
     g.d_top = c.d_lo + m.passes * m.nch * m.nd_per_thread - 1;
-    g.b_lo = c.b_lo;
-    g.b_hi = c.b_hi;
+    g.st.b_lo = c.b_lo;
+    g.st.b_hi = c.b_hi;
     g.tag_bits = tag_bits_for(c);
     g.ox0 = c.ox0;
     g.ox1 = c.ox1;
@@ -451,7 +438,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.tile_stride = m.tile_cols;
     g.strips = m.strips;
     g.prefer_large = c.prefer_large;
-    g.mirror = c.mirror;
+    g.st.mirror = c.mirror;
     g.fallback_neg = c.fallback_neg;
     const MarchFn fn = cost_out ? e->fn_cost : e->fn;
     if (!fn) return hipErrorInvalidValue;
@@ -467,7 +454,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, Plane a, Plane b, 
     g.cost_out = cost_out;
     g.cost_pitch = cost_pitch;
     for (int pass = 0; pass < m.passes; ++pass) {
-        g.d_first = c.d_lo + pass * m.nch * m.nd_per_thread;
+        g.st.d_first = c.d_lo + pass * m.nch * m.nd_per_thread;
         g.pass_mode = m.passes == 1 ? 0 : pass == 0 ? 1 : pass == m.passes - 1 ? 3 : 2;
         hipLaunchKernelGGL(fn, grid, dim3(m.threads), m.lds_bytes, s, g);
     }

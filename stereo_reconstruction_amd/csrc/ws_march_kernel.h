@@ -6,35 +6,52 @@
 #pragma once
 #include "ws_device.h"
 
+#include <stddef.h>
+
 namespace wsamd {
 
 // ------------------------------------------------------------------------------------------
 // the marching kernel
 // ------------------------------------------------------------------------------------------
+// What the stages ahead of the chains read (ws_march_kernel, produce): 16 dwords, one scalar load.  They re-read it from
+// the kernel's argument segment every step instead of keeping ~40 values derived from it in scalar registers across
+// the chains' arithmetic (first version: 60 .. 200 spilled scalar registers per instantiation, a v_readlane each).
+struct StageArgs {
+    // the caller's CV_8UC3 rows (BlockSearch.cpp:41,46,59 reads the same bytes): A carries the outputs, B the candidates
+    const uint8_t *img_a;
+    const uint8_t *img_b;
+    int stride_a, stride_b; // bytes
+    int wa, wb;             // pixels
+    int nxr, nch;
+    int wx0, boff;
+    int d_first; // first disparity of chunk 0 in THIS launch (d_lo + pass * chunks * ND)
+    int mirror;
+    int b_lo, b_hi;
+};
+static_assert(sizeof(StageArgs) == 64, "one s_load_dwordx16");
+
 struct MarchArgs {
-    const uint32_t *A;
-    const uint32_t *B;
-    const int32_t *bias; // SSD only
+    StageArgs st;
     float *out;
     double *out64; // if set: doubles here instead of floats to `out` (CV_64F output without a widening pass)
-    int pitch_a, pad_a, pitch_b, pad_b, pitch_bi, pad_bi, out_pitch;
-    int wa;
-    int nxr, nch;
-    int wx0, wy0, boff;
-    int d_lo, d_hi, b_lo, b_hi;
+    int out_pitch;
+    int border;       // left view: this launch also writes the zeros outside [ox0,ox1) x [oy0,oy1) of the out_w x out_h map
+    int out_w, out_h;
+    int wy0;
+    int d_lo, d_hi;
     int d_top;     // d_lo + passes * chunks * ND - 1: the padded upper end of the range (SSD tie tags count from it)
-    int d_first;   // first disparity of chunk 0 in THIS launch (d_lo + pass * chunks * ND)
     int pass_mode; // 0 = the only pass, 1 = first, 2 = middle, 3 = last of several d-group passes
     void *keys;    // several passes: plane of the best keys so far (slot_t per pixel)
     int keys_pitch;
     int ox0, ox1, oy0, oy1;
     int strip_rows, tiles, strips;
     int tile_stride; // output columns per tile: nxr * X, or (nxr - 1) * X for the halo-exchange kernels (march_pk_halo)
-    int prefer_large, mirror, fallback_neg;
+    int prefer_large, fallback_neg;
     int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
     int32_t *cost_out; // optional (smoothFactor passes): the winner's cost, SSD without the sum of a^2
     int cost_pitch;
 };
+static_assert(offsetof(MarchArgs, st) == 0, "produce() reads StageArgs at the start of the kernel's argument segment");
 
 // LDS row layout.  A thread reads runs of consecutive pixels starting at column X*r; with a
 // plain row-major row the 16 lanes that share a ds_read_b128 cycle sit 4*X bytes apart and fall
@@ -65,41 +82,110 @@ __device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *base
     }
 }
 
-// Asynchronous HBM -> LDS copy of one row (n dwords, 16-byte aligned source) into the region
-// layout: global_load_lds_dwordx4, no VGPR staging.  The LDS address of an LDS-DMA is wave-uniform
-// base (M0) + lane * 16, so consecutive lanes fill consecutive quads of one region and each lane
-// fetches the quad that belongs there (the source address carries the permutation).
+// ---- staging the caller's CV_8UC3 rows ---------------------------------------------------------------------------
+// The reference reads the caller's Mat directly (BlockSearch.cpp:41,46,59); so does this kernel.  Rounds 1-3 ran a
+// pre-pass that rewrote both images as dword planes and box-summed a "bias" plane (8.7 MB in, 20.8 MB out at config 2,
+// 15 % of a pair's device time); now a tile's rows travel HBM -> LDS as the bytes they are and the workgroup unpacks
+// them itself, three stages ahead of their use, one barrier between stages (the barrier every step ends with anyway):
 //
-// The instruction is issued through inline assembly ON PURPOSE: for the builtin the compiler makes
-// every later LDS read of the wave wait for vmcnt(0) (it cannot know the copy fills a ring slot nobody
-// reads in this step), which exposes the copy's whole latency at the top of the arithmetic; here
-// nothing waits until the explicit dma_wait() in front of the step's barrier (A/B on one MI355X,
-// config 2: 171 -> 166 us).  Dealing the copies of a step to different waves, with scalar addressing,
-// measured SLOWER (186-191 us): the loop below leaves them all to the workgroup's first wave.
+//   step a-3  DMA     the 16-byte blocks that hold the tile's bytes of image row a go to a raw LDS buffer
+//                     (global_load_lds_dwordx4, no VGPR staging; the blocks are aligned in HBM, so the tile's first
+//                     byte sits at offset s = address & 15 of the buffer -- any row stride, any base pointer);
+//   step a-2  UNPACK  a lane takes 4 pixels = 12 bytes (4 dwords, v_alignbyte by s & 3, four v_perm) to one 16-byte
+//                     quad of the dword ring (B | G<<8 | R<<16, the layout the chains read), zero outside the image,
+//                     mirrored for the right view; SSD: the same lane moves the quad's four column sums
+//                     G = sum over the window rows of b^2 + the fused chain's correction term
+//                     (G += b_enter^2 - b_leave^2 + 2 K * channel sum of b_leave), kept in LDS;
+//   step a-1  HSUM    SSD: a lane turns 4 + WW - 1 column sums into 4 bias values (running prefix, differences) --
+//                     the box sum of the squared target pixels for the output row of step a;
+//   step a    the chains read the row.
+// ~130 wave-instructions per step beside the ~4000 of the chains at config 2, dealt to the waves that neither issue
+// the copies nor flush the finished row.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// (row_lds: the LDS byte address of the row's first dword -- an integer, taken once per kernel from the shared-memory
-// base: a generic pointer cast to the LDS address space at every call carries a null check that one of the compiler's
-// scheduling strategies could not encode)
-template <int NREG>
-__device__ __forceinline__ void stage_row_async(uint32_t row_lds, int ro, const uint32_t *gsrc, int n, int tid, int nt)
+struct RawSide {         // one image as a tile sees it (wave-uniform)
+    const uint8_t *base; // the caller's rows
+    int stride;          // bytes per row
+    int c0;              // image column behind raw index 0 (may lie outside the image)
+    int v_lo, v_hi;      // raw indices [v_lo, v_hi) are inside the image
+    int nq;              // quads per tile row
+    int mirror;          // logical quad Q = nq - 1 - raw quad, pixels reversed (right view: canonical x = w - 1 - x)
+};
+
+__device__ __forceinline__ RawSide raw_side(const uint8_t *base, int stride, int w, int canon0, int n4, int mirror)
 {
+    RawSide s;
+    s.base = base;
+    s.stride = stride;
+    s.nq = n4 >> 2;
+    s.mirror = mirror;
+    s.c0 = mirror ? w - canon0 - n4 : canon0; // (logical p <-> canonical canon0 + p <-> image w - 1 - canon0 - p = c0 + (n4 - 1 - p))
+    s.v_lo = max(0, -s.c0);
+    s.v_hi = max(s.v_lo, min(n4, w - s.c0)); // (empty when the tile's columns miss the image altogether)
+    return s;
+}
+// address of raw index 0 of image row y (arithmetic only: it may lie before the row when the tile hangs over the image's edge)
+__device__ __forceinline__ uintptr_t raw_origin(const RawSide &s, int y)
+{
+    return reinterpret_cast<uintptr_t>(s.base) + (uintptr_t)((long long)y * s.stride + 3LL * s.c0);
+}
+
+// (row_lds: the LDS byte address of the raw buffer -- an integer, taken once per kernel from the shared-memory base: a
+// generic pointer cast to the LDS address space at every call carries a null check that one of the compiler's
+// scheduling strategies could not encode)
+//
+// The instruction is issued through inline assembly ON PURPOSE: for the builtin the compiler makes every later LDS
+// read of the wave wait for vmcnt(0) (it cannot know the copy fills a buffer nobody reads in this step), which exposes
+// the copy's whole latency at the top of the arithmetic; here nothing waits until the explicit dma_wait() in front of
+// the step's barrier (A/B on one MI355X, config 2, round 1: 171 -> 166 us).
+__device__ __forceinline__ void raw_dma(uint32_t raw_lds, const RawSide &s, int y, int tid, int nt)
+{
+    if (s.v_hi <= s.v_lo) return; // (uniform: the tile's columns of this image are all outside it)
+    const uintptr_t fv = raw_origin(s, y);
+    const uintptr_t a0 = (fv + 3u * (uint32_t)s.v_lo) & ~(uintptr_t)15; // an aligned block that holds a byte of the image
+    const uintptr_t e = fv + 3u * (uint32_t)s.v_hi;                      // stays inside that byte's page
+    const int nblk = (int)((e - a0 + 15) >> 4);
+    const uint32_t dst0 = raw_lds + (uint32_t)(a0 - (fv & ~(uintptr_t)15));
     const int lane = tid & 63;
-    const int nquads = (n + 3) >> 2;
+    for (int idx = tid; idx < nblk; idx += nt) {
+        // M0 is written right in front of its use and put back behind it, inside one statement: the compiler keeps
+        // values of its own in M0 (LDS-DMA builtins, indexed register moves) and is not told otherwise -- M0 is a
+        // reserved register, a clobber of it is refused with a warning
+        const uint32_t la = __builtin_amdgcn_readfirstlane(dst0 + 16u * (uint32_t)(idx - lane));
+        uint32_t saved_m0;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved_m0)
+                     : "v"(reinterpret_cast<const uint8_t *>(a0) + 16 * (size_t)idx), "s"(la)
+                     : "memory");
+    }
+}
+
+// raw quad q (raw indices 4q .. 4q+3) of a row whose raw index 0 sits at byte s of the buffer -> four pixel dwords
+template <bool CENTRED>
+__device__ __forceinline__ void raw_unpack(uint32_t (&px)[4], const uint32_t *raw, uint32_t s, int q, const RawSide &sd)
+{
+    const uint32_t *p = raw + (s >> 2) + 3 * q; // (12 q bytes on: the byte phase s & 3 is the row's)
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+    const uint32_t sh = s & 3u;
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first, 0x0c is a zero byte
+    px[0] = a0 & 0x00ffffffu;
+    px[1] = __builtin_amdgcn_perm(a1, a0, 0x0c050403u);
+    px[2] = __builtin_amdgcn_perm(a2, a1, 0x0c040302u);
+    px[3] = a2 >> 8;
+    if constexpr (CENTRED) {
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) {
-        const int nidx = (nquads - j + NREG - 1) / NREG; // quads of this region
-        for (int idx = tid; idx < nidx; idx += nt) {
-            // M0 is written right in front of its use and put back behind it, inside one statement: the compiler keeps
-            // values of its own in M0 (LDS-DMA builtins, indexed register moves) and is not told otherwise -- M0 is a
-            // reserved register, a clobber of it is refused with a warning
-            const uint32_t la = __builtin_amdgcn_readfirstlane(row_lds + 4u * (uint32_t)(j * ro + 4 * (idx - lane)));
-            uint32_t saved_m0;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(saved_m0)
-                         : "v"(gsrc + 4 * (idx * NREG + j)), "s"(la)
-                         : "memory");
-        }
+        for (int e = 0; e < 4; ++e) px[e] ^= kCentre;
+    }
+    if (sd.v_lo > 0 || sd.v_hi < 4 * sd.nq) { // (uniform: a tile that hangs over the image's edge)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((uint32_t)(4 * q + e - sd.v_lo) >= (uint32_t)(sd.v_hi - sd.v_lo)) px[e] = 0u;
+    }
+    if (sd.mirror) {
+        uint32_t t = px[0]; px[0] = px[3]; px[3] = t;
+        t = px[1]; px[1] = px[2]; px[2] = t;
     }
 }
 
@@ -467,7 +553,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
     constexpr int LT = ilog2c(ND);
     constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
-    constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being filled for the next
+    constexpr int NR = WH + 3; // ring rows: WH+1 in use by a step, one unpacked last step (its bias row is being summed), one being unpacked
     // merge slots: SSD (cost << LT | 7) : global tie tag as one signed 64-bit key, SAD the 32-bit key itself;
     // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
     // (packed SAD: (cost << 16) | global tie tag as an UNSIGNED 32-bit key, cost field 0xffff = no valid candidate)
@@ -480,20 +566,21 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     uint32_t *smem = reinterpret_cast<uint32_t *>(ws_smem4);
 
     const int NT = blockDim.x, tid = threadIdx.x;
-    const int tx = g.nxr * X, dt = g.nch * ND;
+    const int tx = g.st.nxr * X, dt = g.st.nch * ND;
     // pixels of a row the tile's threads read (HALO: nobody reads past the last run's own columns)
     // (the SSD halo kernel keeps the long chains while a strip's window fills: it reads what the plain kernel reads)
-    const int n_a = HALO && PK ? tx : tx + WW - 1, n_b = HALO && PK ? tx + dt - 1 : tx + WW + dt - 2, n_bi = tx + dt - 1;
+    const MarchLds L = march_lds_layout(X, ND, WW, WH, SSD, HALO && PK, g.st.nxr, g.st.nch);
+    const int n_a = L.n_a, n_b = L.n_b, n_bi = L.n_bi;
     const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
     const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
-    const int a_w = NREG * ro_a, b_w = NREGB * ro_b, bi_w = NREGB * ro_bi;
+    const int a_w = L.a_w, b_w = L.b_w, bi_w = L.bi_w;
     uint32_t *ringA = smem;
     uint32_t *ringB = ringA + NR * a_w;
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
     slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
+    // behind the slots (laid out again by the stages themselves, produce): two raw rows of each image -- one landing, one
+    // being unpacked -- and, SSD, the column sums G after the last two unpacked rows
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    const uint32_t ldsA = (uint32_t)(uintptr_t)(lds_u32 *)smem; // LDS byte addresses of the three rings (stage_row_async)
-    const uint32_t ldsB = ldsA + 4u * (uint32_t)(NR * a_w), ldsBi = ldsB + 4u * (uint32_t)(NR * b_w);
 
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (each with its own
     // L2), so ids b and b+8 share one.  Give every XCD a contiguous range of (strip, tile) pairs:
@@ -501,25 +588,45 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int nblk = gridDim.x; // padded to a multiple of 8 by the launcher
     const int logical = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
     if (logical >= g.tiles * g.strips) return; // uniform per workgroup
-    const int tile_x0 = g.ox0 + (logical % g.tiles) * g.tile_stride;
+    const int tile_i = logical % g.tiles, strip_i = logical / g.tiles;
+    const int tile_x0 = g.ox0 + tile_i * g.tile_stride;
     const int tx_out = HALO ? tx - X : tx; // the columns this tile hands out (HALO: the last run only feeds its neighbour)
-    const int ys = g.oy0 + (logical / g.tiles) * g.strip_rows;
+    const int ys = g.oy0 + strip_i * g.strip_rows;
     const int ye = min(ys + g.strip_rows, g.oy1);
     if (ys >= ye) return; // uniform per workgroup
 
-    const int dhi_t = g.d_first + dt - 1;
-    const uint32_t *gA = g.A + (tile_x0 + g.wx0 + g.pad_a);
-    const uint32_t *gB = g.B + (tile_x0 + g.wx0 + g.boff - dhi_t + g.pad_b);
-    const uint32_t *gBi = SSD ? reinterpret_cast<const uint32_t *>(g.bias) + (tile_x0 + g.boff - dhi_t + g.pad_bi) : nullptr;
+    const int dhi_t = g.st.d_first + dt - 1;
+    // left view: the map's pixels outside the marching interior are zeros (BlockSearch.cpp:33,36,38: the loops never
+    // reach them); the tiles along the interior's edge write them -- their stores drain while the strip's window fills
+    if (g.border && (g.pass_mode == 0 || g.pass_mode == 3)) {
+        const bool first_t = tile_i == 0, last_t = tile_i == g.tiles - 1;
+        const int cx0 = first_t ? 0 : tile_x0, cx1 = last_t ? g.out_w : tile_x0 + tx_out;
+        auto zero_rect = [&](int x0, int x1, int y0, int y1) __attribute__((always_inline)) {
+            const int w = x1 - x0, n = w * (y1 - y0);
+            for (int i = tid; i < n; i += NT) {
+                const int yy = y0 + i / w, xx = x0 + i % w;
+                if (g.out64) g.out64[(size_t)yy * g.out_pitch + xx] = 0.0;
+                else g.out[(size_t)yy * g.out_pitch + xx] = 0.0f;
+            }
+        };
+        if (strip_i == 0 && g.oy0 > 0) zero_rect(cx0, cx1, 0, g.oy0);
+        if (strip_i == g.strips - 1 && g.out_h > g.oy1) zero_rect(cx0, cx1, g.oy1, g.out_h);
+        if (first_t && g.ox0 > 0) zero_rect(0, g.ox0, ys, ye);
+        if (last_t && g.out_w > g.ox1) zero_rect(g.ox1, g.out_w, ys, ye);
+    }
 
     for (int k = tid; k < 2 * tx; k += NT) slots[k] = kEmpty;
+    if constexpr (SSD) {
+        uint32_t *gcol = reinterpret_cast<uint32_t *>(slots + 2 * tx) + 2 * (L.rawa_dw + L.rawb_dw);
+        for (int k = tid; k < 2 * L.g_dw; k += NT) gcol[k] = 0u; // (G before the strip's first row)
+    }
 
-    const int r = tid % g.nxr, c = tid / g.nxr;
-    const bool worker = c < g.nch;
+    const int r = tid % g.st.nxr, c = tid / g.st.nxr;
+    const bool worker = c < g.st.nch;
     // run starts (dword offset inside region 0): A at column X*r, B / bias at column X*r + ND*(nch-1-c)
     const int ia = 4 * r;
-    const int ib = 4 * (((X / 4) * r + (ND / 4) * (g.nch - 1 - (worker ? c : 0))) / NREGB);
-    const int d0 = g.d_first + c * ND; // first disparity of this thread's chunk
+    const int ib = 4 * (((X / 4) * r + (ND / 4) * (g.st.nch - 1 - (worker ? c : 0))) / NREGB);
+    const int d0 = g.st.d_first + c * ND; // first disparity of this thread's chunk
     const int shift = SSD ? LT + 1 : g.tag_bits;
     // SSD merge: global tie tag = chunk tag | local tag (a multiple of ND, so one v_and_or builds it):
     // the chunk's distance from the preferred end of the padded range [d_lo, d_top]
@@ -541,17 +648,17 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             if (d > g.d_hi) tagr[j] |= kPkNone;
         }
         // target centre of (x, j): tile_x0 + r X + x - (d0 + j) + boff, i.e. xb0 + m with m = x - j + ND - 1
-        const int xb0 = tile_x0 + r * X - d0 + g.boff - (ND - 1);
-        mk.mlo = g.b_lo - xb0;
-        mk.span = (uint32_t)(g.b_hi - g.b_lo);
-        if (g.b_hi < g.b_lo) { mk.mlo = 1 << 30; mk.span = 0u; } // (no valid centre at all)
+        const int xb0 = tile_x0 + r * X - d0 + g.st.boff - (ND - 1);
+        mk.mlo = g.st.b_lo - xb0;
+        mk.span = (uint32_t)(g.st.b_hi - g.st.b_lo);
+        if (g.st.b_hi < g.st.b_lo) { mk.mlo = 1 << 30; mk.span = 0u; } // (no valid centre at all)
         // Per WAVE: a thread all of whose target centres are out of range poisons its tags instead (free), so only the
         // waves that hold a thread with SOME centres out of range -- the few on the diagonal x - d = b_lo of a tile at
         // the image's edge -- pay the extra v_or per key.  (Wave-uniform: different waves of a workgroup then run
         // different copies of the loops, every copy with the same barriers.)
         const int xb_min = xb0, xb_max = xb0 + X + ND - 2;
-        const bool none_ok = worker && (xb_max < g.b_lo || xb_min > g.b_hi);
-        const bool some_bad = worker && !none_ok && (xb_min < g.b_lo || xb_max > g.b_hi);
+        const bool none_ok = worker && (xb_max < g.st.b_lo || xb_min > g.st.b_hi);
+        const bool some_bad = worker && !none_ok && (xb_min < g.st.b_lo || xb_max > g.st.b_hi);
         if (none_ok) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) tagr[j] |= kPkNone;
@@ -572,8 +679,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 const int tag = g.prefer_large ? g.d_hi - d : d - g.d_lo;
 #pragma unroll
                 for (int x = 0; x < X; ++x) {
-                    const int xb = tile_x0 + r * X + x - d + g.boff;
-                    V[x][j] = (d <= g.d_hi && xb >= g.b_lo && xb <= g.b_hi) ? tag : kPoison;
+                    const int xb = tile_x0 + r * X + x - d + g.st.boff;
+                    V[x][j] = (d <= g.d_hi && xb >= g.st.b_lo && xb <= g.st.b_hi) ? tag : kPoison;
                 }
             }
         }
@@ -582,16 +689,128 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int ra0 = ys + g.wy0; // first window row of the first output row
     const int nsteps = (ye - ys) + WH - 1;
 
-    // prologue: row ra0 (and the bias row of step 0 when the window is one row high)
-    stage_row_async<NREG>(ldsA, ro_a, gA + (size_t)ra0 * g.pitch_a, n_a, tid, NT);
-    stage_row_async<NREGB>(ldsB, ro_b, gB + (size_t)ra0 * g.pitch_b, n_b, tid, NT);
-    if (SSD && WH == 1)
-        stage_row_async<NREGB>(ldsBi, ro_bi, gBi + (size_t)ys * g.pitch_bi, n_bi, tid, NT);
-    dma_wait();
-    __syncthreads();
+    // ---- the stages ahead of the chains (overview above raw_dma): what step a does for the rows to come ----------
+    // Everything a stage needs is derived HERE, every step, from the 16 dwords of StageArgs re-read through a pointer
+    // the compiler cannot see through: a few dozen scalar instructions per step beside ~500 vector ones per wave,
+    // instead of as many scalar registers held (and spilled) across the chains.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int kMul = kFuseSsd ? (CENTRED ? -2 : 510) : 0; // 2 K of the fused chain's correction term (march_fused_ssd)
+    auto produce = [&](int a) __attribute__((always_inline)) {
+        // (the argument segment itself: taking the address of the by-value argument would copy all of it to scratch memory)
+        const StageArgs *sp = (const StageArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(sp));
+        StageArgs st; // (field by field: a struct copy through the opaque pointer went through scratch memory)
+        st.img_a = sp->img_a; st.img_b = sp->img_b; st.stride_a = sp->stride_a; st.stride_b = sp->stride_b;
+        st.wa = sp->wa; st.wb = sp->wb; st.nxr = sp->nxr; st.nch = sp->nch; st.wx0 = sp->wx0; st.boff = sp->boff;
+        st.d_first = sp->d_first; st.mirror = sp->mirror; st.b_lo = sp->b_lo; st.b_hi = sp->b_hi;
+        const MarchLds P = march_lds_layout(X, ND, WW, WH, SSD, HALO && PK, st.nxr, st.nch);
+        const int nwaves = (int)blockDim.x >> 6;
+        // whole waves per role (A quads | B quads | bias quads), dealt to the waves from the second one on: the first
+        // issues the copies, the last ones flush the finished row
+        const int nqa = P.n_a4 >> 2, nqb = P.n_b4 >> 2, nqh = (P.n_bi + 3) >> 2;
+        const int roles_a = (nqa + 63) >> 6, roles_b = (nqb + 63) >> 6, roles_h = SSD ? (nqh + 63) >> 6 : 0;
+        const int role0 = wave == 0 ? nwaves - 1 : wave - 1;
+        if (wave > 1 && role0 >= roles_a + roles_b + roles_h) return; // (the copies fit two waves: 128 blocks of 16 bytes per image)
+        uint32_t *p_ringA = smem, *p_ringB = p_ringA + NR * P.a_w, *p_bias = p_ringB + NR * P.b_w;
+        uint32_t *p_rawA = p_bias + 2 * P.bi_w + 2 * (st.nxr * X) * (int)(sizeof(slot_t) / 4), *p_rawB = p_rawA + 2 * P.rawa_dw;
+        uint32_t *p_gcol = p_rawB + 2 * P.rawb_dw;
+        const int p_tx = st.nxr * X, p_dhi = st.d_first + st.nch * ND - 1;
+        // the tile's columns of both images: logical column 0 of ring A is canonical column tile_x0 + wx0, of ring B (and
+        // of the column sums) tile_x0 + wx0 + boff - dhi_t; bias column k is the target centre tile_x0 + boff - dhi_t + k
+        const RawSide sideA = raw_side(st.img_a, st.stride_a, st.wa, tile_x0 + st.wx0, P.n_a4, st.mirror);
+        const RawSide sideB = raw_side(st.img_b, st.stride_b, st.wb, tile_x0 + st.wx0 + st.boff - p_dhi, P.n_b4, st.mirror);
+        (void)p_tx;
+        // DMA: image row a + 3 of the strip's window rows
+        if (a + 3 < nsteps && wave <= 1) {
+            const int i = a + 3;
+            const int nt_dma = nwaves > 1 ? 128 : 64;
+            raw_dma((uint32_t)(uintptr_t)(lds_u32 *)(p_rawA + (i & 1) * P.rawa_dw), sideA, ra0 + i, tid, nt_dma);
+            raw_dma((uint32_t)(uintptr_t)(lds_u32 *)(p_rawB + (i & 1) * P.rawb_dw), sideB, ra0 + i, tid, nt_dma);
+        }
+        const int iu = a + 2; // UNPACK row iu (it landed before the barrier that ended the last step)
+        const int ih = a + 1; // HSUM: the bias row of the step that adds row ih
+        const bool do_u = iu >= 0 && iu < nsteps, do_h = SSD && ih >= WH - 1 && ih < nsteps;
+        int slot_u = iu % NR, slot_l = (iu + 3) % NR; // ring slots of row iu and of row iu - WH, which leaves the column sums
+        if (slot_u < 0) slot_u += NR;
+        if (slot_l < 0) slot_l += NR;
+        const int ro_ua = march_region_dwords(P.n_a, NREG), ro_ub = march_region_dwords(P.n_b, NREGB);
+        for (int role = role0; role < roles_a + roles_b + roles_h; role += nwaves) {
+            if (role < roles_a) {
+                const int q = role * 64 + lane;
+                if (do_u && q < nqa) {
+                    uint32_t px[4];
+                    raw_unpack<CENTRED>(px, p_rawA + (iu & 1) * P.rawa_dw, (uint32_t)raw_origin(sideA, ra0 + iu) & 15u, q, sideA);
+                    const int Q = st.mirror ? nqa - 1 - q : q;
+                    *reinterpret_cast<uint4 *>(p_ringA + slot_u * P.a_w + (Q % NREG) * ro_ua + (Q / NREG) * 4) = make_uint4(px[0], px[1], px[2], px[3]);
+                }
+            } else if (role < roles_a + roles_b) {
+                const int q = (role - roles_a) * 64 + lane;
+                if (do_u && q < nqb) {
+                    uint32_t px[4];
+                    raw_unpack<CENTRED>(px, p_rawB + (iu & 1) * P.rawb_dw, (uint32_t)raw_origin(sideB, ra0 + iu) & 15u, q, sideB);
+                    const int Q = st.mirror ? nqb - 1 - q : q;
+                    const int phys = (Q % NREGB) * ro_ub + (Q / NREGB) * 4;
+                    *reinterpret_cast<uint4 *>(p_ringB + slot_u * P.b_w + phys) = make_uint4(px[0], px[1], px[2], px[3]);
+                    if constexpr (SSD) {
+                        // the quad's column sums: row iu enters, row iu - WH leaves and joins the correction term
+                        const uint4 gp = *reinterpret_cast<const uint4 *>(p_gcol + ((iu + 1) & 1) * P.g_dw + 4 * Q);
+                        uint32_t gn[4] = {gp.x, gp.y, gp.z, gp.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gn[e] = pix_dot<CENTRED>(px[e], px[e], gn[e]);
+                        if (iu >= WH) {
+                            const uint4 lv = *reinterpret_cast<const uint4 *>(p_ringB + slot_l * P.b_w + phys);
+                            const uint32_t lp[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                gn[e] -= pix_dot<CENTRED>(lp[e], lp[e], 0u);
+                                if constexpr (kMul != 0) gn[e] += (uint32_t)kMul * pix_dot<CENTRED>(lp[e], 0x00010101u, 0u);
+                            }
+                        }
+                        *reinterpret_cast<uint4 *>(p_gcol + (iu & 1) * P.g_dw + 4 * Q) = make_uint4(gn[0], gn[1], gn[2], gn[3]);
+                    }
+                }
+            } else if constexpr (SSD) {
+                const int q = (role - roles_a - roles_b) * 64 + lane;
+                if (do_h && q < nqh) {
+                    // 4 bias values = the sums of WW consecutive column sums each: a running prefix over 4 + WW - 1 of them
+                    constexpr int NV = ((4 + WW - 1 + 3) / 4) * 4;
+                    uint32_t v[NV];
+                    const uint32_t *gr = p_gcol + (ih & 1) * P.g_dw + 4 * q;
+#pragma unroll
+                    for (int m = 0; m < NV / 4; ++m) {
+                        const uint4 t = *reinterpret_cast<const uint4 *>(gr + 4 * m);
+                        v[4 * m] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int m = 1; m < 4 + WW - 1; ++m) v[m] += v[m - 1];
+                    // bias column k is target centre tile_x0 + boff - dhi_t + k: valid inside [b_lo, b_hi], else the key is poisoned
+                    const int k_lo = st.b_lo - (tile_x0 + st.boff - p_dhi);
+                    const bool k_any = st.b_hi >= st.b_lo;
+                    const uint32_t k_span = (uint32_t)(st.b_hi - st.b_lo);
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (v[e + WW - 1] - (e ? v[e - 1] : 0u)) << LT;
+                        if (!k_any || (uint32_t)(4 * q + e - k_lo) > k_span) o[e] += (uint32_t)kPoison;
+                    }
+                    const int oi_h = ih - (WH - 1), ro_ubi = march_region_dwords(P.n_bi, NREGB);
+                    *reinterpret_cast<uint4 *>(p_bias + (oi_h & 1) * P.bi_w + (q % NREGB) * ro_ubi + (q / NREGB) * 4) =
+                        make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    };
+
+    // prologue: three steps of the stages alone -- row 0 lands, is unpacked, (a window one row high: gets its bias row)
+#pragma unroll 1
+    for (int a = -3; a < 0; ++a) {
+        produce(a);
+        dma_wait();
+        __syncthreads();
+    }
 
     int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
-    int sub_slot = 2 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
+    int sub_slot = 3 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
     // image row of the output flushed at step a (row ys + a - WH) sits in slot (a - WH - wy0) mod NR
     int out_slot = ((-WH - g.wy0) % NR + NR) % NR;
 
@@ -603,7 +822,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
         const int k = tid - (NT - round_up_dev(tx, 64));
         if (k >= 0 && k < tx_out) {
-            const int si = (k % X) * g.nxr + k / X; // slots are stored [x][r] (round 3: [r][x] -- a thread's slots as neighbours, one
+            const int si = (k % X) * g.st.nxr + k / X; // slots are stored [x][r] (round 3: [r][x] -- a thread's slots as neighbours, one
                                                     // address for all eight ds_min -- saved 14 instructions a step and lost more to
                                                     // LDS bank conflicts: config 2 0.120 -> 0.125 ms)
             slot_t key = sl[si];
@@ -617,7 +836,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 if (g.pass_mode != 3) *kp = key;
             }
             if (x < g.ox1 && (g.pass_mode == 0 || g.pass_mode == 3)) {
-                const int xo = g.mirror ? g.wa - 1 - x : x;
+                const int xo = g.st.mirror ? g.st.wa - 1 - x : x;
                 float val;
                 const bool none = SSD  ? (int32_t)((long long)key >> 32) >= kValidKeyBound
                                   : PK ? (uint32_t)key >= kPkNone
@@ -629,7 +848,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     val = (float)(g.prefer_large ? (SSD ? g.d_top : g.d_hi) - gtag : g.d_lo + gtag);
                 }
                 // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
-                if (rowA[lds_phys<NREG>(k - g.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
+                if (rowA[lds_phys<NREG>(k - g.st.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
                 if (g.out64) g.out64[(size_t)y * g.out_pitch + xo] = (double)val;
                 else g.out[(size_t)y * g.out_pitch + xo] = val;
                 if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
@@ -653,16 +872,10 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         const int oi = a - (WH - 1); // output row index inside the strip produced by this step
         if constexpr (PHASE == 2) flush(oi);
 
-        // 2. start the copy of the next step's rows into the ring slot nobody reads this step
+        // 2. the stages ahead: copy row a + 3, unpack row a + 2, sum the bias row of step a + 1
         int nxt_slot = add_slot + 1;
         if (nxt_slot == NR) nxt_slot = 0;
-        if (a + 1 < nsteps) {
-            stage_row_async<NREG>(ldsA + 4u * (uint32_t)(nxt_slot * a_w), ro_a, gA + (size_t)(ra0 + a + 1) * g.pitch_a, n_a, tid, NT);
-            stage_row_async<NREGB>(ldsB + 4u * (uint32_t)(nxt_slot * b_w), ro_b, gB + (size_t)(ra0 + a + 1) * g.pitch_b, n_b, tid, NT);
-            if (SSD && oi + 1 >= 0)
-                stage_row_async<NREGB>(ldsBi + 4u * (uint32_t)(((oi + 1) & 1) * bi_w), ro_bi,
-                                      gBi + (size_t)(ys + oi + 1) * g.pitch_bi, n_bi, tid, NT);
-        }
+        produce(a);
 
         // 3. arithmetic
         if (worker) {
@@ -686,7 +899,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 else march_pk<X, ND, WW, PHASE, MASKED>(Vp, bestp, pa, pb, qa, qb, tagr, mks);
                 if constexpr (PHASE >= 1) {
 #pragma unroll
-                    for (int x = 0; x < X; ++x) atomicMin(sl + x * g.nxr, bestp[x]); // ds_min_u32
+                    for (int x = 0; x < X; ++x) atomicMin(sl + x * g.st.nxr, bestp[x]); // ds_min_u32
                 }
             } else {
                 int32_t best[X];
@@ -730,9 +943,9 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                         if constexpr (SSD) {
                             const uint32_t gtag = (uint32_t)(bk & (ND - 1)) | (uint32_t)ctag; // v_and_or_b32
                             const long long key = (long long)(((unsigned long long)(uint32_t)(bk | (ND - 1)) << 32) | gtag);
-                            atomicMin(reinterpret_cast<long long *>(sl) + x * g.nxr, key); // ds_min_i64, lanes on consecutive slots
+                            atomicMin(reinterpret_cast<long long *>(sl) + x * g.st.nxr, key); // ds_min_i64, lanes on consecutive slots
                         } else {
-                            atomicMin(reinterpret_cast<int32_t *>(sl) + x * g.nxr, bk); // ds_min_i32
+                            atomicMin(reinterpret_cast<int32_t *>(sl) + x * g.st.nxr, bk); // ds_min_i32
                         }
                     }
                 }
