@@ -27,20 +27,37 @@ __host__ __device__ constexpr int march_region_dwords(int n, int nreg)
     return 4 * ((((n + 3) >> 2) + nreg - 1) / nreg + 1);
 }
 
-// bytes a raw row buffer needs (ws_march_kernel.h, raw_dma): up to 15 of alignment in front, 3 per pixel, a dword of
-// over-read behind; in dwords, a multiple of 4
-__host__ __device__ constexpr int march_raw_dwords(int n4) { return ((16 + 3 * n4 + 16 + 15) >> 4) << 2; }
-
-// The marching kernel's LDS, as the kernel lays it out and the planner prices it (one definition for both):
-// ring A | ring B | 2 bias rows (SSD) | 2 rows of merge slots | 2 raw rows of each image | 2 rows of column sums (SSD)
+// ---- the marching kernel's LDS (one definition for the kernel and for the planner that prices it) ----------------
+// [stage area, compile-time offsets: 2 raw rows of the reference image | 2 raw rows of the target image | SSD: 2 rows of
+//  column sums]  then  ring A | ring B | 2 bias rows (SSD) | 2 rows of merge slots.
+// The stage area is sized for the widest tile row any plan makes, so that its addresses are immediates in the code of the
+// stages (ws_march_kernel.h, produce) instead of scalar registers held across the chains.
+// bytes a raw row buffer needs (raw_dma): up to 15 of alignment in front, 3 per pixel, a dword of over-read behind
+__host__ __device__ constexpr int march_raw_bytes(int n4) { return ((16 + 3 * n4 + 16 + 15) >> 4) << 4; }
+constexpr int kStageThreads = 512; // the plans' workgroup limit (ws_march_kernel.h: kMaxT)
+// widest rows: nxr * nch <= 512 threads, nxr >= 4 x-runs of 8 columns, 8 <= nch <= 64 d-chunks, windows up to 17 wide
+constexpr int kStageMaxNA = 8 * (kStageThreads / 8) + 16 + 4;
+__host__ __device__ constexpr int march_max_nb(int nd)
+{
+    return (((8 * (kStageThreads / 8) + 8 * nd) > (64 + 64 * nd) ? (8 * (kStageThreads / 8) + 8 * nd) : (64 + 64 * nd)) + 17 + 3 + 3) & ~3;
+}
+__host__ __device__ constexpr int march_stage_bytes(int nd, bool ssd)
+{
+    return 2 * march_raw_bytes(kStageMaxNA) + 2 * march_raw_bytes(march_max_nb(nd)) + (ssd ? 2 * 4 * (march_max_nb(nd) + 16) : 0);
+}
+// The stages' work is dealt to whole waves as ROLES: image B's quads first -- SSD: 16 - NQN owner lanes per row of 16
+// lanes (the row's last NQN lanes only feed the DPP fetches of their neighbours, NQN = the quads to the right whose
+// column sums a quad's bias values need), SAD: 64 per wave -- then image A's, 64 per wave.
+__host__ __device__ constexpr int march_nqn(int ww, bool ssd) { return ssd ? (ww + 2) / 4 : 0; }
 struct MarchLds {
     int n_a, n_b, n_bi;   // pixels of a row the tile's threads read: reference image, target image, bias values
     int n_a4, n_b4;       // ... rounded up to quads (what is unpacked)
     int a_w, b_w, bi_w;   // dwords per ring row (region layout)
-    int rawa_dw, rawb_dw; // dwords per raw row buffer
-    int g_dw;             // dwords per row of column sums
     int nr;               // ring rows
-    int bytes;
+    int roles_b, roles_a; // whole waves of stage work per step
+    int nslots;           // roles a wave takes at most (a 16-byte descriptor per thread and slot)
+    int desc_bytes;
+    int bytes;            // 0: a row wider than the stage area
 };
 __host__ __device__ inline MarchLds march_lds_layout(int x, int nd, int ww, int wh, bool ssd, bool short_runs, int nxr, int nch)
 {
@@ -56,11 +73,15 @@ __host__ __device__ inline MarchLds march_lds_layout(int x, int nd, int ww, int 
     l.a_w = nreg * march_region_dwords(l.n_a, nreg);
     l.b_w = nregb * march_region_dwords(l.n_b, nregb);
     l.bi_w = ssd ? nregb * march_region_dwords(l.n_bi, nregb) : 0;
-    l.rawa_dw = march_raw_dwords(l.n_a4);
-    l.rawb_dw = march_raw_dwords(l.n_b4);
-    l.g_dw = ssd ? l.n_b4 + 16 : 0;
-    l.nr = wh + 3;
-    l.bytes = 4 * (l.nr * (l.a_w + l.b_w) + 2 * l.bi_w + 2 * (l.rawa_dw + l.rawb_dw) + 2 * l.g_dw) + 2 * tx * (ssd ? 8 : 4);
+    l.nr = wh + 2;
+    const int threads = (nxr * nch + 63) / 64 * 64, nwaves = threads / 64;
+    const int qw = ssd ? 4 * (16 - march_nqn(ww, true)) : 64;
+    l.roles_b = (l.n_b4 / 4 + qw - 1) / qw;
+    l.roles_a = (l.n_a4 / 4 + 63) / 64;
+    l.nslots = (l.roles_b + l.roles_a + nwaves - 1) / nwaves;
+    l.desc_bytes = 16 * threads * l.nslots;
+    l.bytes = march_stage_bytes(nd, ssd) + l.desc_bytes + 4 * (l.nr * (l.a_w + l.b_w) + 2 * l.bi_w) + 2 * tx * (ssd ? 8 : 4);
+    if (l.n_a4 > kStageMaxNA || l.n_b4 > march_max_nb(nd)) l.bytes = 0;
     return l;
 }
 

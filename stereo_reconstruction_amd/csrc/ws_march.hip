@@ -317,7 +317,7 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         p.strip_rows = ceil_div(out_h, strips);
         p.strips = ceil_div(out_h, p.strip_rows);
         p.lds_bytes = (size_t)march_lds_layout(X, pnd, c.ww, c.wh, c.ssd != 0, p.halo && !c.ssd && march_pk_window(c.ww, c.wh), runs, p.nch).bytes;
-        if (p.lds_bytes > 160 * 1024) return 0.0;
+        if (p.lds_bytes == 0 || p.lds_bytes > 160 * 1024) return 0.0; // (0: a tile row wider than the kernel's stage area)
         // a row step of the halo-exchange kernel against the plain one's, from the instruction counts (march_pk_halo);
         // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
         // (6.19 against 7.52 instructions per hypothesis at 9 x 9, profiles/r03/isa_op_histogram.txt; a thread of the halo
@@ -440,6 +440,12 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img
     g.prefer_large = c.prefer_large;
     g.st.mirror = c.mirror;
     g.fallback_neg = c.fallback_neg;
+    static const int env_prod = [] { const char *v = getenv("WS_STAGE_WAVE"); return v ? atoi(v) : -1; }();  // development knobs
+    static const int env_flush = [] { const char *v = getenv("WS_FLUSH_WAVE"); return v ? atoi(v) : -1; }();
+    g.tune_prod_wave = env_prod;
+    g.tune_flush_wave = env_flush;
+    static const int env_agap = [] { const char *v = getenv("WS_STAGE_AGAP"); return v ? atoi(v) : 0; }();
+    g.tune_a_gap = env_agap;
     const MarchFn fn = cost_out ? e->fn_cost : e->fn;
     if (!fn) return hipErrorInvalidValue;
     if (m.lds_bytes > 48 * 1024) {

@@ -50,6 +50,9 @@ struct MarchArgs {
     int tag_bits; // SAD: keys are (cost << tag_bits) | global tie tag
     int32_t *cost_out; // optional (smoothFactor passes): the winner's cost, SSD without the sum of a^2
     int cost_pitch;
+    int tune_prod_wave;  // development knobs (WS_STAGE_WAVE / WS_FLUSH_WAVE): the first wave that unpacks / that flushes; -1 = default
+    int tune_flush_wave;
+    int tune_a_gap;
 };
 static_assert(offsetof(MarchArgs, st) == 0, "produce() reads StageArgs at the start of the kernel's argument segment");
 
@@ -86,68 +89,82 @@ __device__ __forceinline__ void lds_run(uint32_t (&dst)[N], const uint32_t *base
 // The reference reads the caller's Mat directly (BlockSearch.cpp:41,46,59); so does this kernel.  Rounds 1-3 ran a
 // pre-pass that rewrote both images as dword planes and box-summed a "bias" plane (8.7 MB in, 20.8 MB out at config 2,
 // 15 % of a pair's device time); now a tile's rows travel HBM -> LDS as the bytes they are and the workgroup unpacks
-// them itself, three stages ahead of their use, one barrier between stages (the barrier every step ends with anyway):
+// them itself, two stages ahead of their use, one barrier between stages (the barrier every step ends with anyway):
 //
-//   step a-3  DMA     the 16-byte blocks that hold the tile's bytes of image row a go to a raw LDS buffer
-//                     (global_load_lds_dwordx4, no VGPR staging; the blocks are aligned in HBM, so the tile's first
-//                     byte sits at offset s = address & 15 of the buffer -- any row stride, any base pointer);
-//   step a-2  UNPACK  a lane takes 4 pixels = 12 bytes (4 dwords, v_alignbyte by s & 3, four v_perm) to one 16-byte
-//                     quad of the dword ring (B | G<<8 | R<<16, the layout the chains read), zero outside the image,
-//                     mirrored for the right view; SSD: the same lane moves the quad's four column sums
-//                     G = sum over the window rows of b^2 + the fused chain's correction term
-//                     (G += b_enter^2 - b_leave^2 + 2 K * channel sum of b_leave), kept in LDS;
-//   step a-1  HSUM    SSD: a lane turns 4 + WW - 1 column sums into 4 bias values (running prefix, differences) --
-//                     the box sum of the squared target pixels for the output row of step a;
+//   step a-2  DMA      the 16-byte blocks that hold the tile's bytes of image row a go to a raw LDS buffer
+//                      (global_load_lds_dwordx4, no VGPR staging; the blocks are aligned in HBM, so the tile's first
+//                      byte sits at offset s = address & 15 of the buffer -- any row stride, any base pointer);
+//   step a-1  PRODUCE  a lane takes 4 pixels = 12 bytes (4 dwords, v_alignbyte by s & 3, three v_perm) to one 16-byte
+//                      quad of the dword ring (B | G<<8 | R<<16, the layout the chains read), zero outside the image,
+//                      mirrored for the right view.  SSD: the same lane moves the quad's four column sums
+//                      G = sum over the window rows of b^2 + the fused chain's correction term (kept in LDS), and --
+//                      with the sums of the next lanes, fetched by DPP inside the additions -- turns 4 + WW - 1 of them
+//                      into the 4 bias values of the output row of step a (running prefix, differences);
 //   step a    the chains read the row.
-// ~130 wave-instructions per step beside the ~4000 of the chains at config 2, dealt to the waves that neither issue
-// the copies nor flush the finished row.
+// What counts is instructions per WAVE and step: a wave issues one instruction every ~5 cycles whatever it is, and the
+// step ends when the slowest wave reaches the barrier.  (The first version computed its addresses from the kernel's
+// arguments every step -- ~150 scalar instructions in every producing wave -- and had a third stage for the bias rows:
+// the kernel took 168 us instead of 117 at config 2.)  Hence: the raw buffers and the column sums sit at COMPILE-TIME
+// LDS addresses (a stage area sized for the widest tile row, ws_device.h), a wave's roles are fixed for the kernel's
+// life, and what varies per step is a handful of scalars.
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-struct RawSide {         // one image as a tile sees it (wave-uniform)
+struct RawSide {         // one image as a tile sees it (wave-uniform; used while the kernel sets itself up)
     const uint8_t *base; // the caller's rows
     int stride;          // bytes per row
     int c0;              // image column behind raw index 0 (may lie outside the image)
     int v_lo, v_hi;      // raw indices [v_lo, v_hi) are inside the image
     int nq;              // quads per tile row
-    int mirror;          // logical quad Q = nq - 1 - raw quad, pixels reversed (right view: canonical x = w - 1 - x)
 };
 
+// mirror (right view: canonical x = w - 1 - x): logical p <-> canonical canon0 + p <-> image column c0 + (n4 - 1 - p),
+// i.e. raw quad q holds logical quad nq - 1 - q, pixels reversed
 __device__ __forceinline__ RawSide raw_side(const uint8_t *base, int stride, int w, int canon0, int n4, int mirror)
 {
     RawSide s;
     s.base = base;
     s.stride = stride;
     s.nq = n4 >> 2;
-    s.mirror = mirror;
-    s.c0 = mirror ? w - canon0 - n4 : canon0; // (logical p <-> canonical canon0 + p <-> image w - 1 - canon0 - p = c0 + (n4 - 1 - p))
+    s.c0 = mirror ? w - canon0 - n4 : canon0;
     s.v_lo = max(0, -s.c0);
     s.v_hi = max(s.v_lo, min(n4, w - s.c0)); // (empty when the tile's columns miss the image altogether)
     return s;
 }
-// address of raw index 0 of image row y (arithmetic only: it may lie before the row when the tile hangs over the image's edge)
-__device__ __forceinline__ uintptr_t raw_origin(const RawSide &s, int y)
+
+// what a wave that issues the copies of one image keeps (scalars)
+struct RawDma {
+    uintptr_t f0;     // address of the first byte inside the image of the strip's first window row
+    uint32_t stride;  // bytes per image row
+    uint32_t nbytes;  // bytes inside the image per tile row (0: none)
+    uint32_t off3;    // 3 * v_lo: raw index 0 sits that many bytes before f0
+};
+__device__ __forceinline__ RawDma raw_dma_setup(const RawSide &s, int y0)
 {
-    return reinterpret_cast<uintptr_t>(s.base) + (uintptr_t)((long long)y * s.stride + 3LL * s.c0);
+    RawDma d;
+    d.f0 = reinterpret_cast<uintptr_t>(s.base) + (uintptr_t)((long long)y0 * s.stride + 3LL * (s.c0 + s.v_lo));
+    d.stride = (uint32_t)s.stride;
+    d.nbytes = 3u * (uint32_t)(s.v_hi - s.v_lo);
+    d.off3 = 3u * (uint32_t)s.v_lo;
+    return d;
 }
 
-// (row_lds: the LDS byte address of the raw buffer -- an integer, taken once per kernel from the shared-memory base: a
-// generic pointer cast to the LDS address space at every call carries a null check that one of the compiler's
-// scheduling strategies could not encode)
+// Row i of the strip: every 16-byte block that holds a byte of the tile's columns -> the raw buffer at LDS byte address
+// raw_lds, so that raw index 0's first byte lands at offset (its address & 15).
 //
-// The instruction is issued through inline assembly ON PURPOSE: for the builtin the compiler makes every later LDS
-// read of the wave wait for vmcnt(0) (it cannot know the copy fills a buffer nobody reads in this step), which exposes
-// the copy's whole latency at the top of the arithmetic; here nothing waits until the explicit dma_wait() in front of
-// the step's barrier (A/B on one MI355X, config 2, round 1: 171 -> 166 us).
-__device__ __forceinline__ void raw_dma(uint32_t raw_lds, const RawSide &s, int y, int tid, int nt)
+// (raw_lds: an integer, not a pointer -- a generic pointer cast to the LDS address space at every call carries a null
+// check that one of the compiler's scheduling strategies could not encode.)  The instruction is issued through inline
+// assembly ON PURPOSE: for the builtin the compiler makes every later LDS read of the wave wait for vmcnt(0) (it cannot
+// know the copy fills a buffer nobody reads in this step), which exposes the copy's whole latency at the top of the
+// arithmetic; here nothing waits until the explicit dma_wait() in front of the step's barrier (A/B on one MI355X,
+// config 2, round 1: 171 -> 166 us).
+__device__ __forceinline__ void raw_dma(uint32_t raw_lds, const RawDma &d, int i, int lane)
 {
-    if (s.v_hi <= s.v_lo) return; // (uniform: the tile's columns of this image are all outside it)
-    const uintptr_t fv = raw_origin(s, y);
-    const uintptr_t a0 = (fv + 3u * (uint32_t)s.v_lo) & ~(uintptr_t)15; // an aligned block that holds a byte of the image
-    const uintptr_t e = fv + 3u * (uint32_t)s.v_hi;                      // stays inside that byte's page
-    const int nblk = (int)((e - a0 + 15) >> 4);
-    const uint32_t dst0 = raw_lds + (uint32_t)(a0 - (fv & ~(uintptr_t)15));
-    const int lane = tid & 63;
-    for (int idx = tid; idx < nblk; idx += nt) {
+    if (d.nbytes == 0) return; // (uniform: the tile's columns of this image are all outside it)
+    const uintptr_t f = d.f0 + (uintptr_t)((uint32_t)i * d.stride);
+    const uintptr_t a0 = f & ~(uintptr_t)15;                     // an aligned block that holds a byte of the image
+    const int nblk = (int)((((uint32_t)f & 15u) + d.nbytes + 15u) >> 4); // stays inside that byte's page
+    const uint32_t dst0 = raw_lds + (((uint32_t)f & ~15u) - (((uint32_t)f - d.off3) & ~15u));
+    for (int idx = lane; idx < nblk; idx += 64) {
         // M0 is written right in front of its use and put back behind it, inside one statement: the compiler keeps
         // values of its own in M0 (LDS-DMA builtins, indexed register moves) and is not told otherwise -- M0 is a
         // reserved register, a clobber of it is refused with a warning
@@ -160,13 +177,28 @@ __device__ __forceinline__ void raw_dma(uint32_t raw_lds, const RawSide &s, int 
     }
 }
 
-// raw quad q (raw indices 4q .. 4q+3) of a row whose raw index 0 sits at byte s of the buffer -> four pixel dwords
-template <bool CENTRED>
-__device__ __forceinline__ void raw_unpack(uint32_t (&px)[4], const uint32_t *raw, uint32_t s, int q, const RawSide &sd)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t ws_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ws_u32x4 lds_u128;
+// LDS accesses by byte address (a 32-bit integer: no generic pointer, no null check, immediates fold into the offset field)
+__device__ __forceinline__ const lds_u32 *lds_at32(uint32_t byte_addr) { return reinterpret_cast<const lds_u32 *>((uintptr_t)byte_addr); }
+__device__ __forceinline__ uint4 lds_load128(uint32_t byte_addr)
 {
-    const uint32_t *p = raw + (s >> 2) + 3 * q; // (12 q bytes on: the byte phase s & 3 is the row's)
+    const ws_u32x4 v = *reinterpret_cast<const lds_u128 *>((uintptr_t)byte_addr); // ds_read_b128
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_store128(uint32_t byte_addr, uint4 v)
+{
+    ws_u32x4 t = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<lds_u128 *>((uintptr_t)byte_addr) = t; // ds_write_b128
+}
+
+// 12 bytes at LDS byte address `at` (dword aligned) + byte phase sh (0..3) -> four pixel dwords, in memory order
+template <bool CENTRED>
+__device__ __forceinline__ void raw_unpack(uint32_t (&px)[4], uint32_t at, uint32_t sh)
+{
+    const lds_u32 *p = lds_at32(at);
     const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-    const uint32_t sh = s & 3u;
     const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
                    a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
     // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first, 0x0c is a zero byte
@@ -178,15 +210,13 @@ __device__ __forceinline__ void raw_unpack(uint32_t (&px)[4], const uint32_t *ra
 #pragma unroll
         for (int e = 0; e < 4; ++e) px[e] ^= kCentre;
     }
-    if (sd.v_lo > 0 || sd.v_hi < 4 * sd.nq) { // (uniform: a tile that hangs over the image's edge)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if ((uint32_t)(4 * q + e - sd.v_lo) >= (uint32_t)(sd.v_hi - sd.v_lo)) px[e] = 0u;
-    }
-    if (sd.mirror) {
-        uint32_t t = px[0]; px[0] = px[3]; px[3] = t;
-        t = px[1]; px[1] = px[2]; px[2] = t;
-    }
+}
+
+// lane + n's value inside a row of 16 lanes (n = 1 .. 15; lanes past the row's end read 0)
+template <int N>
+__device__ __forceinline__ uint32_t from_lane_plus(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x100 + N, 0xf, 0xf, true); // row_shl:N
 }
 
 // One row entering (SIGN=+1) or leaving (SIGN=-1) the window of every (column, disparity) this
@@ -553,7 +583,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     constexpr int NREG = X / 4, NREGB = march_nreg_b(X, ND);
     constexpr int LT = ilog2c(ND);
     constexpr bool CENTRED = SSD && ssd_needs_centring(WW, WH, ND);
-    constexpr int NR = WH + 3; // ring rows: WH+1 in use by a step, one unpacked last step (its bias row is being summed), one being unpacked
+    constexpr int NR = WH + 2; // ring rows: WH+1 in use by a step, 1 being unpacked for the next
     // merge slots: SSD (cost << LT | 7) : global tie tag as one signed 64-bit key, SAD the 32-bit key itself;
     // a key at or above kValidKeyBound (in its cost word) is "no valid candidate"
     // (packed SAD: (cost << 16) | global tie tag as an UNSIGNED 32-bit key, cost field 0xffff = no valid candidate)
@@ -574,13 +604,18 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int ro_a = march_region_dwords(n_a, NREG), ro_b = march_region_dwords(n_b, NREGB);
     const int ro_bi = SSD ? march_region_dwords(n_bi, NREGB) : 0;
     const int a_w = L.a_w, b_w = L.b_w, bi_w = L.bi_w;
-    uint32_t *ringA = smem;
+    // the stage area first, at compile-time offsets (ws_device.h): two raw rows of each image -- one landing, one being
+    // unpacked -- and, SSD, the column sums G after the last two unpacked rows
+    constexpr int kRA = march_raw_bytes(kStageMaxNA), kRB = march_raw_bytes(march_max_nb(ND));
+    constexpr int kGB = SSD ? 4 * (march_max_nb(ND) + 16) : 0;
+    constexpr int oRawA = 0, oRawB = 2 * kRA, oG = 2 * kRA + 2 * kRB, kStage = march_stage_bytes(ND, SSD);
+    static_assert(kStage == oG + 2 * kGB && kStage % 16 == 0, "stage area");
+    static_assert(MAXT <= kStageThreads, "the stage area is sized for workgroups of up to kStageThreads");
+    uint32_t *ringA = smem + (kStage + L.desc_bytes) / 4; // (behind the stage area: the stages' per-thread descriptors)
     uint32_t *ringB = ringA + NR * a_w;
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
     slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
-    // behind the slots (laid out again by the stages themselves, produce): two raw rows of each image -- one landing, one
-    // being unpacked -- and, SSD, the column sums G after the last two unpacked rows
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32 *)smem; // LDS byte address of the stage area
 
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (each with its own
     // L2), so ids b and b+8 share one.  Give every XCD a contiguous range of (strip, tile) pairs:
@@ -616,9 +651,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     }
 
     for (int k = tid; k < 2 * tx; k += NT) slots[k] = kEmpty;
-    if constexpr (SSD) {
-        uint32_t *gcol = reinterpret_cast<uint32_t *>(slots + 2 * tx) + 2 * (L.rawa_dw + L.rawb_dw);
-        for (int k = tid; k < 2 * L.g_dw; k += NT) gcol[k] = 0u; // (G before the strip's first row)
+    if constexpr (SSD) { // (G before the strip's first row, both parities)
+        for (int k = tid; k < L.n_b4 + 16; k += NT) smem[oG / 4 + k] = smem[(oG + kGB) / 4 + k] = 0u;
     }
 
     const int r = tid % g.st.nxr, c = tid / g.st.nxr;
@@ -690,127 +724,220 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     const int nsteps = (ye - ys) + WH - 1;
 
     // ---- the stages ahead of the chains (overview above raw_dma): what step a does for the rows to come ----------
-    // Everything a stage needs is derived HERE, every step, from the 16 dwords of StageArgs re-read through a pointer
-    // the compiler cannot see through: a few dozen scalar instructions per step beside ~500 vector ones per wave,
-    // instead of as many scalar registers held (and spilled) across the chains.
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    constexpr int kMul = kFuseSsd ? (CENTRED ? -2 : 510) : 0; // 2 K of the fused chain's correction term (march_fused_ssd)
-    auto produce = [&](int a) __attribute__((always_inline)) {
-        // (the argument segment itself: taking the address of the by-value argument would copy all of it to scratch memory)
-        const StageArgs *sp = (const StageArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(sp));
-        StageArgs st; // (field by field: a struct copy through the opaque pointer went through scratch memory)
-        st.img_a = sp->img_a; st.img_b = sp->img_b; st.stride_a = sp->stride_a; st.stride_b = sp->stride_b;
-        st.wa = sp->wa; st.wb = sp->wb; st.nxr = sp->nxr; st.nch = sp->nch; st.wx0 = sp->wx0; st.boff = sp->boff;
-        st.d_first = sp->d_first; st.mirror = sp->mirror; st.b_lo = sp->b_lo; st.b_hi = sp->b_hi;
-        const MarchLds P = march_lds_layout(X, ND, WW, WH, SSD, HALO && PK, st.nxr, st.nch);
-        const int nwaves = (int)blockDim.x >> 6;
-        // whole waves per role (A quads | B quads | bias quads), dealt to the waves from the second one on: the first
-        // issues the copies, the last ones flush the finished row
-        const int nqa = P.n_a4 >> 2, nqb = P.n_b4 >> 2, nqh = (P.n_bi + 3) >> 2;
-        const int roles_a = (nqa + 63) >> 6, roles_b = (nqb + 63) >> 6, roles_h = SSD ? (nqh + 63) >> 6 : 0;
-        const int role0 = wave == 0 ? nwaves - 1 : wave - 1;
-        if (wave > 1 && role0 >= roles_a + roles_b + roles_h) return; // (the copies fit two waves: 128 blocks of 16 bytes per image)
-        uint32_t *p_ringA = smem, *p_ringB = p_ringA + NR * P.a_w, *p_bias = p_ringB + NR * P.b_w;
-        uint32_t *p_rawA = p_bias + 2 * P.bi_w + 2 * (st.nxr * X) * (int)(sizeof(slot_t) / 4), *p_rawB = p_rawA + 2 * P.rawa_dw;
-        uint32_t *p_gcol = p_rawB + 2 * P.rawb_dw;
-        const int p_tx = st.nxr * X, p_dhi = st.d_first + st.nch * ND - 1;
+    // Set up once: a 16-byte DESCRIPTOR per thread and role in LDS -- where the lane's 12 raw bytes sit, where its quad
+    // goes, which of its pixels lie inside the image, whether it owns what it computes.  A step then costs a producing
+    // wave one ds_read_b128, a handful of scalar instructions and the arithmetic itself; nothing of the geometry below
+    // stays in registers across the chains.
+    //   x: raw buffer byte offset of the quad's 12 bytes (+ the row's byte phase & ~3, + the parity's buffer)
+    //   y: byte offset of the quad inside a ring row | the same inside a bias row << 16
+    //   z: byte offset of the quad's column sums (+ the parity's buffer)
+    //   w: kDescRing: owns the ring quad (and its column sums), kDescBias: owns the bias quad,
+    //      bits 8..11: pixel e lies inside the image, bits 12..15: bias value e belongs to an invalid target centre
+    constexpr uint32_t kDescRing = 1u, kDescBias = 2u;
+    constexpr int NQN = march_nqn(WW, SSD); // quads to the right whose column sums a quad's bias values need
+    static_assert(NQN < 8, "a row of 16 lanes holds a quad and its neighbours");
+    constexpr int QROW = 16 - NQN, QW = SSD ? 4 * QROW : 64; // owner lanes per row of 16, quads per role-wave
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = NT >> 6, lane = tid & 63;
+    // Roles go to the waves from `pw0` on, and so does the flush: behind the two waves that issue the copies in a
+    // workgroup of 8 waves, from the first wave on in smaller ones.  Measured, not derived (profiles/r04/stage_waves.txt):
+    // the same work dealt otherwise costs config 2 up to 16 % (0.128 .. 0.151 ms) -- the waves with work at the top of a
+    // step start their chains late, out of step with the other waves' bursts of LDS reads.
+    const int pw0 = g.tune_prod_wave >= 0 ? g.tune_prod_wave % nwaves : (nwaves > 4 ? 2 : 0);
+    const int role0 = wave >= pw0 ? wave - pw0 : wave - pw0 + nwaves;
+    const int agap = g.tune_a_gap > 0 && L.nslots == 1 && L.roles_b + L.roles_a + g.tune_a_gap <= nwaves ? g.tune_a_gap : 0;
+    uint32_t wkinds = 0; // two bits per slot of this wave: 1 = image B, 2 = image A
+    uint32_t sflags = 0; // 1: image B hangs over the image's edge, 2: image A does, 4: some target centre of the tile is invalid
+    RawDma dmaMine;      // COPIES: the first wave issues image A's, the second image B's (a lone wave both)
+    uint32_t ph;         // byte phases of raw index 0 in the row to unpack next: A | B << 8 | A's step << 16 | B's step << 24
+    {
         // the tile's columns of both images: logical column 0 of ring A is canonical column tile_x0 + wx0, of ring B (and
         // of the column sums) tile_x0 + wx0 + boff - dhi_t; bias column k is the target centre tile_x0 + boff - dhi_t + k
-        const RawSide sideA = raw_side(st.img_a, st.stride_a, st.wa, tile_x0 + st.wx0, P.n_a4, st.mirror);
-        const RawSide sideB = raw_side(st.img_b, st.stride_b, st.wb, tile_x0 + st.wx0 + st.boff - p_dhi, P.n_b4, st.mirror);
-        (void)p_tx;
-        // DMA: image row a + 3 of the strip's window rows
-        if (a + 3 < nsteps && wave <= 1) {
-            const int i = a + 3;
-            const int nt_dma = nwaves > 1 ? 128 : 64;
-            raw_dma((uint32_t)(uintptr_t)(lds_u32 *)(p_rawA + (i & 1) * P.rawa_dw), sideA, ra0 + i, tid, nt_dma);
-            raw_dma((uint32_t)(uintptr_t)(lds_u32 *)(p_rawB + (i & 1) * P.rawb_dw), sideB, ra0 + i, tid, nt_dma);
-        }
-        const int iu = a + 2; // UNPACK row iu (it landed before the barrier that ended the last step)
-        const int ih = a + 1; // HSUM: the bias row of the step that adds row ih
-        const bool do_u = iu >= 0 && iu < nsteps, do_h = SSD && ih >= WH - 1 && ih < nsteps;
-        int slot_u = iu % NR, slot_l = (iu + 3) % NR; // ring slots of row iu and of row iu - WH, which leaves the column sums
-        if (slot_u < 0) slot_u += NR;
-        if (slot_l < 0) slot_l += NR;
-        const int ro_ua = march_region_dwords(P.n_a, NREG), ro_ub = march_region_dwords(P.n_b, NREGB);
-        for (int role = role0; role < roles_a + roles_b + roles_h; role += nwaves) {
-            if (role < roles_a) {
-                const int q = role * 64 + lane;
-                if (do_u && q < nqa) {
-                    uint32_t px[4];
-                    raw_unpack<CENTRED>(px, p_rawA + (iu & 1) * P.rawa_dw, (uint32_t)raw_origin(sideA, ra0 + iu) & 15u, q, sideA);
-                    const int Q = st.mirror ? nqa - 1 - q : q;
-                    *reinterpret_cast<uint4 *>(p_ringA + slot_u * P.a_w + (Q % NREG) * ro_ua + (Q / NREG) * 4) = make_uint4(px[0], px[1], px[2], px[3]);
+        const RawSide sideA = raw_side(g.st.img_a, g.st.stride_a, g.st.wa, tile_x0 + g.st.wx0, L.n_a4, g.st.mirror);
+        const RawSide sideB = raw_side(g.st.img_b, g.st.stride_b, g.st.wb, tile_x0 + g.st.wx0 + g.st.boff - dhi_t, L.n_b4, g.st.mirror);
+        const int nqa = L.n_a4 >> 2, nqb = L.n_b4 >> 2, nqh = (n_bi + 3) >> 2;
+        dmaMine = raw_dma_setup(wave == 0 ? sideA : sideB, ra0);
+        const uint32_t phA0 = (uint32_t)(reinterpret_cast<uintptr_t>(sideA.base) + (uintptr_t)((long long)ra0 * sideA.stride + 3LL * sideA.c0)) & 15u;
+        const uint32_t phB0 = (uint32_t)(reinterpret_cast<uintptr_t>(sideB.base) + (uintptr_t)((long long)ra0 * sideB.stride + 3LL * sideB.c0)) & 15u;
+        ph = phA0 | phB0 << 8 | ((uint32_t)sideA.stride & 15u) << 16 | ((uint32_t)sideB.stride & 15u) << 24;
+        const int k_lo = g.st.b_lo - (tile_x0 + g.st.boff - dhi_t);
+        const uint32_t k_span = g.st.b_hi >= g.st.b_lo ? (uint32_t)(g.st.b_hi - g.st.b_lo) : 0u;
+        const bool k_none = g.st.b_hi < g.st.b_lo;
+        if (sideB.v_lo > 0 || sideB.v_hi < L.n_b4) sflags |= 1u;
+        if (sideA.v_lo > 0 || sideA.v_hi < L.n_a4) sflags |= 2u;
+        if (k_none || k_lo > 0 || (uint32_t)(4 * nqh - 1 - k_lo) > k_span) sflags |= 4u;
+        for (int slot = 0; slot < L.nslots; ++slot) {
+            // (image A's roles `gap` places behind image B's: development knob WS_STAGE_AGAP, to put them on chosen waves)
+            const int role_raw = slot * nwaves + role0;
+            const int role = role_raw < L.roles_b ? role_raw : role_raw - agap >= L.roles_b ? role_raw - agap : L.roles_b + L.roles_a;
+            uint4 d = make_uint4(0u, 0u, 0u, 0u);
+            if (role < L.roles_b) {
+                wkinds |= 1u << (2 * slot);
+                const int li = SSD ? (lane & 15) : lane, row = SSD ? (lane >> 4) : 0;
+                const int Qr = role * QW + row * QROW + li;
+                const int Q = min(Qr, nqb - 1); // (lanes past the tile row compute on its last quad and store nothing)
+                const int qraw = g.st.mirror ? nqb - 1 - Q : Q;
+                d.x = (uint32_t)oRawB + 12u * (uint32_t)qraw;
+                d.y = (4u * (uint32_t)((Q % NREGB) * ro_b) + 16u * (uint32_t)(Q / NREGB)) |
+                      (4u * (uint32_t)((Q % NREGB) * ro_bi) + 16u * (uint32_t)(Q / NREGB)) << 16;
+                d.z = (uint32_t)oG + 16u * (uint32_t)Q;
+                const bool owner = (!SSD || li < QROW) && Qr < nqb;
+                d.w = (owner ? kDescRing : 0u) | (owner && Q < nqh ? kDescBias : 0u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((uint32_t)(4 * qraw + e - sideB.v_lo) < (uint32_t)(sideB.v_hi - sideB.v_lo)) d.w |= 0x100u << e;
+                    if (k_none || (uint32_t)(4 * Q + e - k_lo) > k_span) d.w |= 0x1000u << e;
                 }
-            } else if (role < roles_a + roles_b) {
-                const int q = (role - roles_a) * 64 + lane;
-                if (do_u && q < nqb) {
+            } else if (role < L.roles_b + L.roles_a) {
+                wkinds |= 2u << (2 * slot);
+                const int Qr = (role - L.roles_b) * 64 + lane;
+                const int Q = min(Qr, nqa - 1);
+                const int qraw = g.st.mirror ? nqa - 1 - Q : Q;
+                d.x = (uint32_t)oRawA + 12u * (uint32_t)qraw;
+                d.y = 4u * (uint32_t)((Q % NREG) * ro_a) + 16u * (uint32_t)(Q / NREG);
+                d.w = Qr < nqa ? kDescRing : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((uint32_t)(4 * qraw + e - sideA.v_lo) < (uint32_t)(sideA.v_hi - sideA.v_lo)) d.w |= 0x100u << e;
+            }
+            lds_store128(lds0 + (uint32_t)kStage + 16u * (uint32_t)(slot * NT + tid), d);
+        }
+    }
+    constexpr int kMul = kFuseSsd ? (CENTRED ? -2 : 510) : 0; // 2 K of the fused chain's correction term (march_fused_ssd)
+    const bool lone = nwaves == 1;
+
+    // what this wave does in a step: 1 = issues image A's copies, 2 = image B's, 4 = image B's by the lone wave, 8 = unpacks
+    const uint32_t wdo = (wave == 0 ? 1u : 0u) | (wave == 1 ? 2u : 0u) | (lone ? 4u : 0u) | (wkinds != 0 ? 8u : 0u);
+
+    // slot_u: the ring slot of row a + 1
+    auto produce = [&](int a_in, int slot_in) __attribute__((always_inline)) {
+        if (wdo == 0) return; // (most waves: one scalar compare per step)
+        // (what follows is computed HERE, every step: hoisted to the top of the loop it would run in every wave)
+        int a = a_in, slot_u = slot_in;
+        asm volatile("" : "+s"(a), "+s"(slot_u));
+        if ((wdo & 7u) && a + 2 < nsteps) { // row a + 2 of the strip: its bytes start their way to the raw buffer of its parity
+            const uint32_t par2 = (uint32_t)(a & 1);
+            if (wdo & 1u) raw_dma(lds0 + (uint32_t)oRawA + par2 * (uint32_t)kRA, dmaMine, a + 2, lane);
+            if (wdo & 2u) raw_dma(lds0 + (uint32_t)oRawB + par2 * (uint32_t)kRB, dmaMine, a + 2, lane);
+            if (wdo & 4u) { // (a workgroup of one wave, tiny images: image B's geometry again, every step)
+                // (read through the argument segment itself: taking the address of the by-value argument copies all of it to scratch)
+                const StageArgs *sp = (const StageArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(sp));
+                const int dt_ = sp->nch * ND, n_b4_ = (sp->nxr * X + (HALO && PK ? 0 : WW - 1) + dt_ - 1 + 3) & ~3;
+                const RawSide sb = raw_side(sp->img_b, sp->stride_b, sp->wb, tile_x0 + sp->wx0 + sp->boff - (sp->d_first + dt_ - 1), n_b4_, sp->mirror);
+                raw_dma(lds0 + (uint32_t)oRawB + par2 * (uint32_t)kRB, raw_dma_setup(sb, ra0), a + 2, lane);
+            }
+        }
+        const int iu = a + 1; // the row the chains add in the next step
+        if (iu < 0 || iu >= nsteps || !(wdo & 8u)) return;
+        {
+            const uint32_t par = (uint32_t)(iu & 1);
+            uint32_t daddr = lds0 + (uint32_t)kStage + 16u * (uint32_t)tid;
+            for (uint32_t kk = wkinds; kk != 0; kk >>= 2, daddr += 16u * (uint32_t)NT) {
+                const uint4 d = lds_load128(daddr);
+                if (kk & 1u) {
+                    // ---- image B: a quad of the ring, its column sums, its bias values
+                    const uint32_t sB = (ph >> 8) & 15u;
                     uint32_t px[4];
-                    raw_unpack<CENTRED>(px, p_rawB + (iu & 1) * P.rawb_dw, (uint32_t)raw_origin(sideB, ra0 + iu) & 15u, q, sideB);
-                    const int Q = st.mirror ? nqb - 1 - q : q;
-                    const int phys = (Q % NREGB) * ro_ub + (Q / NREGB) * 4;
-                    *reinterpret_cast<uint4 *>(p_ringB + slot_u * P.b_w + phys) = make_uint4(px[0], px[1], px[2], px[3]);
+                    raw_unpack<CENTRED>(px, lds0 + d.x + par * (uint32_t)kRB + (sB & ~3u), sB & 3u);
+                    if (sflags & 1u) { // (uniform: a tile that hangs over the image's edge)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) px[e] &= (uint32_t)__builtin_amdgcn_sbfe((int)d.w, 8 + e, 1);
+                    }
+                    if (g.st.mirror) {
+                        uint32_t t = px[0]; px[0] = px[3]; px[3] = t;
+                        t = px[1]; px[1] = px[2]; px[2] = t;
+                    }
+                    const uint32_t phys = d.y & 0xffffu;
+                    const uint32_t ringB_u = lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * a_w + slot_u * b_w);
+                    if (d.w & kDescRing) lds_store128(ringB_u + phys, make_uint4(px[0], px[1], px[2], px[3]));
                     if constexpr (SSD) {
-                        // the quad's column sums: row iu enters, row iu - WH leaves and joins the correction term
-                        const uint4 gp = *reinterpret_cast<const uint4 *>(p_gcol + ((iu + 1) & 1) * P.g_dw + 4 * Q);
+                        // column sums: row iu enters, row iu - WH leaves and joins the correction term.  Plain bytes: with
+                        // x = 255 - b per channel, -b^2 + 510 b = 3 * 255^2 - x.x, so the sums are kept WITHOUT the constant
+                        // (G'' = G - 3 * 255^2 * rows left so far) and a leaving pixel costs an xor, a dot and a subtraction;
+                        // the bias values get WW times the constant back below
+                        const uint4 gp = lds_load128(lds0 + d.z + (par ^ 1u) * (uint32_t)kGB);
                         uint32_t gn[4] = {gp.x, gp.y, gp.z, gp.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) gn[e] = pix_dot<CENTRED>(px[e], px[e], gn[e]);
                         if (iu >= WH) {
-                            const uint4 lv = *reinterpret_cast<const uint4 *>(p_ringB + slot_l * P.b_w + phys);
+                            int slot_l = slot_u + 2; // row iu - WH
+                            if (slot_l >= NR) slot_l -= NR;
+                            const uint4 lv = lds_load128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * a_w + slot_l * b_w) + phys);
                             const uint32_t lp[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                gn[e] -= pix_dot<CENTRED>(lp[e], lp[e], 0u);
-                                if constexpr (kMul != 0) gn[e] += (uint32_t)kMul * pix_dot<CENTRED>(lp[e], 0x00010101u, 0u);
+                                if constexpr (kMul == 510) {
+                                    const uint32_t xc = lp[e] ^ 0x00ffffffu;
+                                    gn[e] -= pix_dot<false>(xc, xc, 0u);
+                                } else {
+                                    gn[e] -= pix_dot<CENTRED>(lp[e], lp[e], 0u);
+                                    if constexpr (kMul != 0) gn[e] += (uint32_t)kMul * pix_dot<CENTRED>(lp[e], 0x00010101u, 0u);
+                                }
                             }
                         }
-                        *reinterpret_cast<uint4 *>(p_gcol + (iu & 1) * P.g_dw + 4 * Q) = make_uint4(gn[0], gn[1], gn[2], gn[3]);
-                    }
-                }
-            } else if constexpr (SSD) {
-                const int q = (role - roles_a - roles_b) * 64 + lane;
-                if (do_h && q < nqh) {
-                    // 4 bias values = the sums of WW consecutive column sums each: a running prefix over 4 + WW - 1 of them
-                    constexpr int NV = ((4 + WW - 1 + 3) / 4) * 4;
-                    uint32_t v[NV];
-                    const uint32_t *gr = p_gcol + (ih & 1) * P.g_dw + 4 * q;
+                        if (d.w & kDescRing) lds_store128(lds0 + d.z + par * (uint32_t)kGB, make_uint4(gn[0], gn[1], gn[2], gn[3]));
+                        if (iu >= WH - 1) {
+                            // 4 bias values = the sums of WW consecutive column sums each: a running prefix over 4 + WW - 1 of
+                            // them, the ones past this quad from the next lanes (every lane of the wave is here: DPP reads them)
+                            uint32_t pre[4 + WW - 1];
+                            pre[0] = gn[0];
 #pragma unroll
-                    for (int m = 0; m < NV / 4; ++m) {
-                        const uint4 t = *reinterpret_cast<const uint4 *>(gr + 4 * m);
-                        v[4 * m] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
-                    }
+                            for (int m = 1; m < 4 + WW - 1; ++m) {
+                                uint32_t v;
+                                if (m < 4) v = gn[m];
+                                else if (m / 4 == 1) v = from_lane_plus<1>(gn[m & 3]);
+                                else if (m / 4 == 2) v = from_lane_plus<2>(gn[m & 3]);
+                                else if (m / 4 == 3) v = from_lane_plus<3>(gn[m & 3]);
+                                else if (m / 4 == 4) v = from_lane_plus<4>(gn[m & 3]);
+                                else v = from_lane_plus<5>(gn[m & 3]);
+                                pre[m] = pre[m - 1] + v;
+                            }
+                            const uint32_t cst = kMul == 510 ? ((uint32_t)(WW * 3 * 255 * 255) * (uint32_t)max(0, iu - WH + 1)) << LT : 0u;
+                            uint32_t o[4];
 #pragma unroll
-                    for (int m = 1; m < 4 + WW - 1; ++m) v[m] += v[m - 1];
-                    // bias column k is target centre tile_x0 + boff - dhi_t + k: valid inside [b_lo, b_hi], else the key is poisoned
-                    const int k_lo = st.b_lo - (tile_x0 + st.boff - p_dhi);
-                    const bool k_any = st.b_hi >= st.b_lo;
-                    const uint32_t k_span = (uint32_t)(st.b_hi - st.b_lo);
-                    uint32_t o[4];
+                            for (int e = 0; e < 4; ++e) o[e] = ((pre[e + WW - 1] - (e ? pre[e - 1] : 0u)) << LT) + cst;
+                            if (sflags & 4u) { // (uniform: a tile with target centres outside [b_lo, b_hi]: their keys are poisoned)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[e] = (v[e + WW - 1] - (e ? v[e - 1] : 0u)) << LT;
-                        if (!k_any || (uint32_t)(4 * q + e - k_lo) > k_span) o[e] += (uint32_t)kPoison;
+                                for (int e = 0; e < 4; ++e) o[e] += __builtin_amdgcn_ubfe(d.w, 12 + e, 1) << 29;
+                            }
+                            static_assert(kPoison == 1 << 29, "the descriptor's poison bits are shifted into place");
+                            if (d.w & kDescBias)
+                                lds_store128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * (a_w + b_w) + ((iu + WH + 1) & 1) * bi_w) + (d.y >> 16),
+                                             make_uint4(o[0], o[1], o[2], o[3]));
+                        }
                     }
-                    const int oi_h = ih - (WH - 1), ro_ubi = march_region_dwords(P.n_bi, NREGB);
-                    *reinterpret_cast<uint4 *>(p_bias + (oi_h & 1) * P.bi_w + (q % NREGB) * ro_ubi + (q / NREGB) * 4) =
-                        make_uint4(o[0], o[1], o[2], o[3]);
+                } else {
+                    // ---- image A: a quad of the ring
+                    const uint32_t sA = ph & 15u;
+                    uint32_t px[4];
+                    raw_unpack<CENTRED>(px, lds0 + d.x + par * (uint32_t)kRA + (sA & ~3u), sA & 3u);
+                    if (sflags & 2u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) px[e] &= (uint32_t)__builtin_amdgcn_sbfe((int)d.w, 8 + e, 1);
+                    }
+                    if (g.st.mirror) {
+                        uint32_t t = px[0]; px[0] = px[3]; px[3] = t;
+                        t = px[1]; px[1] = px[2]; px[2] = t;
+                    }
+                    if (d.w & kDescRing)
+                        lds_store128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(slot_u * a_w) + d.y, make_uint4(px[0], px[1], px[2], px[3]));
                 }
             }
         }
+        // the next row's byte phases: each image's own step, modulo 16
+        ph = (ph & 0xffff0000u) | (((ph & 0x0f0fu) + ((ph >> 16) & 0x0f0fu)) & 0x0f0fu);
     };
 
-    // prologue: three steps of the stages alone -- row 0 lands, is unpacked, (a window one row high: gets its bias row)
+    // prologue: two steps of the stages alone -- row 0 lands, then is unpacked while row 1 lands
 #pragma unroll 1
-    for (int a = -3; a < 0; ++a) {
-        produce(a);
-        dma_wait();
+    for (int a = -2; a < 0; ++a) {
+        produce(a, 0);
+        if (wdo & 7u) dma_wait();
         __syncthreads();
     }
 
     int add_slot = 0;      // ring slot of the row entering at this step   (a     mod NR)
-    int sub_slot = 3 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
+    int sub_slot = 2 % NR; // ring slot of the row leaving at this step    (a-WH  mod NR)
     // image row of the output flushed at step a (row ys + a - WH) sits in slot (a - WH - wy0) mod NR
     int out_slot = ((-WH - g.wy0) % NR + NR) % NR;
 
@@ -819,8 +946,8 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         const int y = ys + oi - 1;
         slot_t *sl = slots + ((oi - 1) & 1) * tx;
         const uint32_t *rowA = ringA + out_slot * a_w;
-        // (the workgroup's first wave issues the row copies: the flush goes to its LAST waves; tx <= NT)
-        const int k = tid - (NT - round_up_dev(tx, 64));
+        // (tx <= NT; which waves flush: see pw0)
+        const int k = tid - 64 * min(g.tune_flush_wave >= 0 ? g.tune_flush_wave : pw0, nwaves - (round_up_dev(tx, 64) >> 6));
         if (k >= 0 && k < tx_out) {
             const int si = (k % X) * g.st.nxr + k / X; // slots are stored [x][r] (round 3: [r][x] -- a thread's slots as neighbours, one
                                                     // address for all eight ds_min -- saved 14 instructions a step and lost more to
@@ -872,10 +999,10 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         const int oi = a - (WH - 1); // output row index inside the strip produced by this step
         if constexpr (PHASE == 2) flush(oi);
 
-        // 2. the stages ahead: copy row a + 3, unpack row a + 2, sum the bias row of step a + 1
+        // 2. the stages ahead: copy row a + 2, unpack row a + 1 (and sum its bias row)
         int nxt_slot = add_slot + 1;
         if (nxt_slot == NR) nxt_slot = 0;
-        produce(a);
+        produce(a, nxt_slot);
 
         // 3. arithmetic
         if (worker) {
@@ -952,7 +1079,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             }
         }
 
-        dma_wait(); // the row copies issued at the top of this step have long landed
+        if (wdo & 7u) dma_wait(); // the row copies issued at the top of this step have long landed (the other waves' stores need not)
         __syncthreads();
         add_slot = nxt_slot;
         if (++sub_slot == NR) sub_slot = 0;
