@@ -125,9 +125,10 @@ int ws_plan(const ws_params *p, const ws_image *left, const ws_image *right, int
  * and rectification_main.cpp:194-195.
  * out: h1 x w1 (LEFT) or h2 x w2 (RIGHT, LINEAR) elements of out_dtype, out_stride in
  * elements.  Copies in, runs, copies out, returns when the map is complete.  Pageable buffers cross
- * through pinned staging memory of the library's (with WS_HOST_REGISTER=1 in the environment they are
- * registered with the HIP runtime for the duration of the call instead) -- every entry point taking host
- * buffers does that; a buffer the caller has pinned itself is used as it is.
+ * through pinned staging memory of the library's -- every entry point taking host buffers does that, and none
+ * registers caller memory with the HIP runtime; a buffer the caller has pinned itself is used as it is
+ * (INTEGRATION.md section 2).  An integer-valued map crosses PCIe as 16-bit integers and is widened to out_dtype
+ * on the host (ws_last_wire_format).
  */
 int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left,
                    const ws_image *right, void *out, int out_stride, int out_dtype);
@@ -227,13 +228,21 @@ int ws_set_host_bands(ws_context *ctx, int bands);
 int ws_device_status(ws_context *ctx, void *stream);
 /*
  * How the bytes of the last host call's three buffers (left, right, out; for a batch: of its last pair) crossed:
- * 0 = not a linear span (gathered rows), 1 = registered by this library for the duration of the call (only with
- * WS_HOST_REGISTER=1), 2 = memory the
- * caller (or a framework) had pinned already, used as it is, 3 = through pinned staging memory of the library
- * (INTEGRATION.md section 2 says when).  Stands in for nothing in the reference (cv::Mat buffers are pageable and
- * rectification.cpp:66-88 never leaves the host); for tests and reports.
+ * 0 = not a linear span (gathered rows), 2 = memory the caller (or a framework) had pinned already, used as it is,
+ * 3 = through pinned staging memory of the library (pageable memory always does: this library registers no caller
+ * memory).  (1 = registered by this library: rounds 2-3 only, never returned any more.)
+ * Stands in for nothing in the reference (cv::Mat buffers are pageable and rectification.cpp:66-88 never leaves the
+ * host); for tests and reports.
  */
 int ws_last_host_paths(const ws_context *ctx, int how[3]);
+/*
+ * The format the last ws_search_host call's map crossed PCIe in: 1 = 16-bit integers (every value a search stores is
+ * an integer in [-width, max(maxDisparity, width)], BlockSearch.cpp:33,82,174 -- taken whenever those bounds fit 16
+ * bits and the search kernels write the map themselves: smoothFactor 1, no sub-pixel refine, no varBlock), widened to
+ * the caller's CV_32F / CV_64F on the host inside the copy out of the staging memory; 2 = float32.  Doubles never
+ * cross.  The map the caller gets is the same either way; for tests and reports.
+ */
+int ws_last_wire_format(const ws_context *ctx, int *wire);
 /*
  * Which kernels the last ws_remove_disparity_outliers call ran: 0 = the double-precision box filter, 1 = the 32-bit
  * integer one (every value of the map an integer in [0, 255] and kernel_size <= 4000: what reconstruction.cpp:5-18 is

@@ -40,7 +40,7 @@ EXPORTS = ["ws_version", "ws_params_default", "ws_create", "ws_destroy", "ws_las
            "ws_warp_nearest_device", "ws_remove_disparity_outliers", "ws_convert_disparity_to_depth",
            "ws_back_project", "ws_write_mesh_off",
            "ws_timer_begin", "ws_timer_end", "ws_set_profiling", "ws_last_kernel_ms",
-           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands", "ws_last_host_paths", "ws_last_outliers_path", "ws_device_status",
+           "ws_last_launch_info", "ws_last_max_block", "ws_set_tuning", "ws_set_host_bands", "ws_last_host_paths", "ws_last_wire_format", "ws_last_outliers_path", "ws_device_status",
            "ws_pfm_read", "ws_pfm_write", "ws_free", "ws_ppm_read", "ws_ppm_write", "ws_calib_read", "ws_evaldisp"]
 
 
@@ -141,6 +141,7 @@ def load_library(build_if_missing=False):
     lib.ws_set_tuning.argtypes = [vp, ci, ci, ci]
     lib.ws_set_host_bands.argtypes = [vp, ci]
     lib.ws_last_host_paths.argtypes = [vp, P(ci)]
+    lib.ws_last_wire_format.argtypes = [vp, P(ci)]
     lib.ws_last_outliers_path.argtypes = [vp, P(ci)]
     lib.ws_device_status.argtypes = [vp, vp]
     lib.ws_pfm_read.argtypes = [ctypes.c_char_p, P(P(ctypes.c_float)), P(ci), P(ci)]
@@ -244,13 +245,19 @@ class WindowSearch:
         return outs
 
     # -- device buffers (torch tensors already in HBM) -------------------------------------
-    def search_device(self, params, left_t, right_t, out_t, stream=None):
-        """left_t/right_t: uint8 CUDA tensors H x W x 3 (contiguous rows); out_t: float32 H x W."""
+    def search_device(self, params, left_t, right_t, out_t, stream=None, check=False):
+        """left_t/right_t: uint8 CUDA tensors H x W x 3 (contiguous rows); out_t: float32 H x W.
+        Only enqueues.  The one thing a kernel can report after the fact -- the left view's smoothFactor raster pass
+        giving up on the band above it, the map is then invalid -- surfaces in the next call that synchronises:
+        device_status(stream), or this call with check=True (waits for the stream and raises).  A caller that
+        synchronises with torch alone must call device_status() before trusting a left-view smoothFactor != 1 map."""
         Li = _Image(left_t.data_ptr(), left_t.shape[1], left_t.shape[0], left_t.stride(0))
         Ri = _Image(right_t.data_ptr(), right_t.shape[1], right_t.shape[0], right_t.stride(0))
         self._check(self._lib.ws_search_device(self._h, ctypes.byref(params), ctypes.byref(Li),
                                                ctypes.byref(Ri), out_t.data_ptr(), out_t.stride(0),
                                                ctypes.c_void_p(stream or 0)))
+        if check:
+            self.device_status(stream)
 
     def warp_nearest(self, src, matrix, dst_shape):
         """cv::warpPerspective(src, dst, matrix, dst_size, INTER_NEAREST) on a float64 map."""
@@ -319,10 +326,17 @@ class WindowSearch:
         self._check(self._lib.ws_device_status(self._h, ctypes.c_void_p(stream or 0)))
 
     def last_host_paths(self):
-        """How the last host call's (left, right, out) bytes crossed: 'gathered', 'registered', 'caller-pinned', 'staged'."""
+        """How the last host call's (left, right, out) bytes crossed: 'gathered', 'caller-pinned', 'staged'
+        ('registered': rounds 2-3 only -- the library registers no caller memory any more)."""
         how = (ctypes.c_int * 3)()
         self._check(self._lib.ws_last_host_paths(self._h, how))
         return tuple(("gathered", "registered", "caller-pinned", "staged")[v] for v in how)
+
+    def last_wire_format(self):
+        """The format the last ws_search_host map crossed PCIe in: 'int16' (widened on the host) or 'float32'."""
+        v = ctypes.c_int(0)
+        self._check(self._lib.ws_last_wire_format(self._h, ctypes.byref(v)))
+        return ("same", "int16", "float32")[v.value]
 
     def last_outliers_path(self):
         """Which box filter the last remove_disparity_outliers ran: 'double', 'integer', 'integer-then-double'."""

@@ -31,7 +31,7 @@ struct RingArgs {
     int ssd, centred;
     int skip_x0, skip_x1, skip_y0, skip_y1; // marching interior, ORIGINAL coordinates
     float *out;
-    double *out64; // if set: doubles here instead of floats to `out`
+    int16_t *out16; // if set: 16-bit integers here instead of floats to `out`
     int out_pitch;
     int32_t *cost_out; // optional: the winner's cost (SSD: without the sum of a^2), for the smoothFactor passes
     int cost_pitch;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
             float val = 0.0f;
             if (y < g.height && g.A[(size_t)y * g.pitch_a + (g.wa - 1 - x) + g.pad_a] != black)
                 val = k == LLONG_MAX ? -(float)x : (float)(uint32_t)(k & 0xffffffffll);
-            if (g.out64) g.out64[(size_t)y * g.out_pitch + x] = (double)val;
+            if (g.out16) g.out16[(size_t)y * g.out_pitch + x] = (int16_t)(int)val;
             else g.out[(size_t)y * g.out_pitch + x] = val;
             if (g.cost_out && k != LLONG_MAX) g.cost_out[(size_t)y * g.cost_pitch + x] = (int32_t)(k >> 32);
         }
@@ -234,7 +234,7 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
         g.skip_x0 = g.skip_x1 = 0;
         g.skip_y0 = g.skip_y1 = c.ha;
     }
-    g.out = out; g.out64 = skip.out64; g.out_pitch = out_pitch;
+    g.out = out; g.out16 = skip.out16; g.out_pitch = out_pitch;
     g.cost_out = cost_out; g.cost_pitch = cost_pitch;
     if (g.half > kRingMaxHalf) return hipErrorInvalidValue;
     const int xtiles = ceil_div(c.wa, kRingTile);
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) ws_linear_kernel(const GenericArgs g)
         }
         val = (float)bd;
     }
-    if (g.out64) g.out64[(size_t)y * g.out_pitch + x] = (double)val;
+    if (g.out16) g.out16[(size_t)y * g.out_pitch + x] = (int16_t)(int)val;
     else g.out[(size_t)y * g.out_pitch + x] = val;
 }
 

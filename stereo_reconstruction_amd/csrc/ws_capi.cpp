@@ -6,6 +6,7 @@
 #include "ws_kernels.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,8 +39,9 @@ struct HostBuf { // pinned host memory of the library's own (hipHostMalloc)
 struct Job { // one pair in flight on the batched host path
     uint8_t *d_in = nullptr; // left image, then right image (rows with the caller's stride)
     float *d_out = nullptr;
-    double *d_out64 = nullptr;
-    size_t in_cap = 0, out_cap = 0; // bytes of d_in; elements of d_out / d_out64
+    int16_t *d_out16 = nullptr;
+    size_t in_cap = 0, out_cap = 0; // bytes of d_in; elements of d_out / d_out16
+    int wire = 0;            // the wire format this pair's map comes down in
     hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
     void *user_out = nullptr;
     int w = 0, h = 0, out_stride = 0, dtype = 0;
@@ -73,42 +75,26 @@ hipError_t host_ensure(HostBuf &b, size_t bytes)
 
 
 // ---- caller host buffers ----------------------------------------------------------------------------------------
-// A copy from / to pageable memory blocks the calling thread for its whole duration and cannot overlap anything
-// (profiles/r02/pcie_probe.txt), so the boundary calls register the caller's buffers while their copies run.  What
-// the runtime does with registrations on this platform was measured, one scenario per process, by
-// tools/ubench/hostreg_probe.hip (profiles/r03/hostreg_probe.txt):
-//   * hipHostRegister accepts ranges that repeat, overlap or share a page with live registrations, but its map of
-//     host allocations has ONE key per base pointer: the same pointer registered under two sizes is one entry;
-//   * hipHostUnregister(p) with p inside a registered range but not itself a key of that map ENDS THE PROCESS
-//     (rocclr device.cpp:373 "Memobj map does not have ptr", abort(): one line on stderr, which a test runner that
-//     captures file descriptor 2 swallows with the process) -- e.g. the second release of a pointer registered
-//     under two sizes while a larger registration that starts below it is alive.  Round 2's registry was keyed by
-//     (pointer, size) and could issue exactly that sequence (crops of one image in a batch); with nothing around
-//     the pointer the same call merely returns hipErrorHostMemoryNotRegistered, which round 2 ignored;
-//   * a copy that starts inside a registered range and runs past its end is refused (hipErrorInvalidValue), it does
-//     not fall back to the pageable path;
-//   * a whole hipHostMalloc'd block cannot be registered again (hipErrorInvalidValue), a part of one can;
-//   * hipHostUnregister waits for copies in flight; the first registration of a range costs 0.1-1 ms (page
-//     faults included), the same range again about 1 us.
-// Rules that follow, enforced by HostRanges below:
-//   1. this library registers page-aligned ranges that are pairwise DISJOINT; a request inside a live range of its
-//      own shares it (reference count), buffers of one call whose pages overlap are registered as one hull;
-//   2. it only ever unregisters base pointers it registered itself, once, and reports a failing status;
-//   3. memory the runtime already knows (the caller's own hipHostMalloc / hipHostRegister, a framework's pinned
-//      allocator) is never registered or released here: copies use it as it is;
-//   4. whatever cannot be registered under 1-3 (partial overlap with a live range, a range the runtime knows in
-//      part, a refused registration or a refused direct copy) crosses through pinned staging memory of the
-//      library's own -- never through the runtime's pageable copy path.
-struct OwnRange { uintptr_t lo, hi; int refs; };
-std::mutex g_host_mutex;
-std::vector<OwnRange> g_own; // disjoint; each one is exactly one hipHostRegister(lo, hi - lo) made here
-
-uintptr_t host_page()
-{
-    static const uintptr_t ps = [] { const long v = sysconf(_SC_PAGESIZE); return v > 0 ? (uintptr_t)v : (uintptr_t)4096; }();
-    return ps;
-}
-
+// This library registers NO caller memory (no hipHostRegister / hipHostUnregister anywhere in it).  Round 2 registered
+// the caller's buffers for the duration of a call; round 3 found what that costs inside somebody else's process -- the
+// runtime abort()s on an unregister of a pointer that lies inside another live registration (rocclr device.cpp:373,
+// tools/ubench/hostreg_probe.hip, profiles/r03/hostreg_probe.txt), and two full test runs ended in a GPU memory fault on
+// a host heap page whose cause was never proven -- and made it opt-in; round 4 removed it: the 16-bit
+// wire format below wins back more than the registration saved.  How bytes cross now:
+//   * pageable memory (a cv::Mat, a numpy array) crosses through pinned staging memory of the library's own
+//     (hipHostMalloc): one host copy each way, on a small pool of threads, band by band beside the transfers;
+//   * memory the runtime already knows at both ends -- the caller's own hipHostMalloc / hipHostRegister, a framework's
+//     pinned allocator -- is used as it is, never registered or released here;
+//   * a range the runtime knows only in part goes through the stage (a direct copy across its edge would be refused).
+// Never through the runtime's pageable copy path: it blocks the calling thread for the whole transfer
+// (profiles/r02/pcie_probe.txt).
+//
+// WIRE FORMAT of a disparity map: every value a search stores is an integer in [-w, max(maxDisparity, w)]
+// (BlockSearch.cpp:33,82,174; LinearSearch.cpp:53) unless the sub-pixel extension is on.  So the map crosses PCIe as
+// 16-bit integers (the search kernels store them: GenericArgs::out16) whenever the bounds fit, and is widened to the
+// caller's CV_32F / CV_64F inside the stage -> caller copy the pool already performs: 2 instead of 4 / 8 bytes per
+// pixel on the bus (config 2, CV_64F: 3 MB instead of 12), exact.  Maps that are not integers (sub-pixel) or that
+// other kernels read back (smoothFactor, varBlock) cross as float32; doubles never cross.
 bool runtime_knows(uintptr_t q)
 {
     hipPointerAttribute_t a;
@@ -120,149 +106,36 @@ bool runtime_knows(uintptr_t q)
     return a.type != hipMemoryTypeUnregistered;
 }
 
+enum Wire { kWireSame = 0, kWireI16 = 1, kWireF32 = 2 }; // what sits in the stage: the caller's own bytes, int16, float32
+
 // One caller buffer for the duration of a call (or of a batch): how its bytes cross.
 struct HostSpan {
-    enum How { kUnused, kOurs, kCallerPinned, kStaged };
+    enum How { kUnused, kOurs /* (rounds 2-3: registered by this library; never set any more) */, kCallerPinned, kStaged };
     uint8_t *p = nullptr;
     size_t n = 0;
     How how = kUnused;
-    uintptr_t own_lo = 0;     // kOurs: the registration it shares
     HostBuf *stage = nullptr; // where its bytes cross if they cannot cross directly (set by the call site, always)
     bool loaded = false;      // uploads: the stage holds the caller's bytes
-    struct Seg { size_t stage_off, host_off, row_bytes, rows, host_pitch; };
-    std::vector<Seg> down;    // downloads that went to the stage: handed to the caller by spans_finish
-    const char *why = "";     // kStaged: the reason (tests, ws_host_path_info)
+    // a download that went to the stage: `rows` rows of `row_elems` elements, dense in the stage from byte stage_off on
+    // in wire format, to the caller's buffer from byte host_off on, rows host_pitch bytes apart, in elements of esz bytes
+    struct Seg { size_t stage_off, host_off, row_elems, rows, host_pitch; int wire; int esz; };
+    std::vector<Seg> down;    // handed to the caller by spans_finish / span_scatter_seg
+    const char *why = "";     // kStaged: the reason (tests, ws_last_host_paths)
 };
 
-// Classify and register the buffers of one call.  Spans with p == nullptr or n == 0 stay kUnused.
-// may_register: false for buffers that stay attached while the CALLER'S code runs (ws_enqueue_host ... ws_wait): those
-// are never registered, see ws_enqueue_host.
-// hipHostRegister on the caller's pageable buffers for the duration of a call saves a host copy each way (config 2:
-// 0.39 instead of the staged figure in DESIGN.md 3.5), and every sequence of calls the probe ran was clean
-// (tools/ubench/hostreg_probe.hip).  But twice in round 3 a full test run -- hundreds of register / unregister cycles
-// on heap pages that numpy and PyTorch reuse for their own pageable copies -- ended in a GPU memory fault on a HOST heap
-// address long after the last registration was released (the second time inside a device-resident search that touches
-// no host memory at all: only the runtime's own copy path could have held that mapping).  A library cannot rule out what
-// else the process does with those pages, so by default pageable memory crosses through the library's pinned stages;
-// memory the caller pinned itself (hipHostMalloc / hipHostRegister / torch pin_memory) crosses directly.
-static bool host_register_allowed()
+// Classify the buffers of one call.  Spans with p == nullptr or n == 0 stay kUnused.
+void spans_attach(HostSpan *sp, int count)
 {
-    static const bool allowed = [] {
-        const char *e = getenv("WS_HOST_REGISTER");
-        return e && atoi(e) == 1;
-    }();
-    return allowed;
-}
-
-void spans_attach(HostSpan *sp, int count, std::string *note, bool may_register = true)
-{
-    // Registering the caller's pageable memory is OFF unless asked for (WS_HOST_REGISTER=1): see host_register_allowed()
-    if (!host_register_allowed()) may_register = false;
-    const uintptr_t ps = host_page();
-    struct Hull { uintptr_t lo, hi; };
-    std::vector<Hull> hulls;
-    std::vector<int> hull_of((size_t)count, -1);
-    // buffers of this call whose page ranges overlap (left / right views of one array, small buffers on one page)
-    // become one hull, registered once
     for (int i = 0; i < count; ++i) {
         if (!sp[i].p || !sp[i].n) continue;
         const uintptr_t a = reinterpret_cast<uintptr_t>(sp[i].p);
-        Hull h{a & ~(ps - 1), (a + sp[i].n + ps - 1) & ~(ps - 1)};
-        int into = -1;
-        for (size_t k = 0; k < hulls.size(); ++k) {
-            if (h.lo < hulls[k].hi && hulls[k].lo < h.hi) {
-                if (into < 0) {
-                    hulls[k].lo = std::min(hulls[k].lo, h.lo);
-                    hulls[k].hi = std::max(hulls[k].hi, h.hi);
-                    into = (int)k;
-                    h = hulls[k];
-                } else { // h (now part of hull `into`) also reaches hull k: fold k into it
-                    hulls[(size_t)into].lo = std::min(hulls[(size_t)into].lo, hulls[k].lo);
-                    hulls[(size_t)into].hi = std::max(hulls[(size_t)into].hi, hulls[k].hi);
-                    for (int j = 0; j < i; ++j) if (hull_of[(size_t)j] == (int)k) hull_of[(size_t)j] = into;
-                    hulls[k].lo = hulls[k].hi = 0; // (emptied, keeps the indices stable)
-                    h = hulls[(size_t)into];
-                }
-            }
-        }
-        if (into < 0) { hulls.push_back(h); into = (int)hulls.size() - 1; }
-        hull_of[(size_t)i] = into;
-    }
-    std::lock_guard<std::mutex> lock(g_host_mutex);
-    for (size_t k = 0; k < hulls.size(); ++k) {
-        const Hull h = hulls[k];
-        if (h.lo == h.hi) continue;
-        HostSpan::How how = HostSpan::kStaged;
-        const char *why = "";
-        uintptr_t own = 0;
-        bool done = false;
-        if (may_register)
-            for (OwnRange &r : g_own) // inside a live range of ours: shared
-                if (r.lo <= h.lo && h.hi <= r.hi) { ++r.refs; how = HostSpan::kOurs; own = r.lo; done = true; break; }
-        if (!done)
-            for (const OwnRange &r : g_own)
-                if (h.lo < r.hi && r.lo < h.hi) {
-                    why = may_register ? "overlaps a live registration of this library in part"
-                                       : "overlaps a registration another call of this library holds right now";
-                    done = true;
-                    break;
-                }
-        if (!done) {
-            // what the runtime knows already is the caller's (or a framework's): never registered or released here
-            bool first = true, all = true, any = false;
-            for (int i = 0; i < count; ++i) {
-                if (hull_of[(size_t)i] != (int)k) continue;
-                const uintptr_t a = reinterpret_cast<uintptr_t>(sp[i].p);
-                const bool k0 = runtime_knows(a), k1 = runtime_knows(a + sp[i].n - 1);
-                all = all && k0 && k1;
-                any = any || k0 || k1;
-                first = false;
-            }
-            any = any || runtime_knows(h.lo) || runtime_knows(h.hi - 1);
-            if (!first && all) {
-                how = HostSpan::kCallerPinned;
-            } else if (any) {
-                why = "the runtime knows a part of the range (registered or allocated by the caller)";
-            } else if (!may_register) {
-                why = "pageable memory in a batch: registrations do not outlive a call of this library";
-            } else {
-                const hipError_t e = hipHostRegister(reinterpret_cast<void *>(h.lo), h.hi - h.lo, hipHostRegisterDefault);
-                if (e == hipSuccess) {
-                    // The runtime resolves an address to the registration with the nearest base below it and looks no
-                    // further: a registration of the caller's INSIDE this range (neither end of it, so not seen above)
-                    // would shadow ours for every byte behind its base -- copies there would be refused or take the
-                    // pageable path.  Ours is clean iff its last byte resolves to an object of exactly its size.
-                    hipDeviceptr_t base = nullptr;
-                    size_t size = 0;
-                    if (hipMemGetAddressRange(&base, &size, reinterpret_cast<hipDeviceptr_t>(h.hi - 1)) == hipSuccess && size == h.hi - h.lo) {
-                        g_own.push_back({h.lo, h.hi, 1});
-                        how = HostSpan::kOurs;
-                        own = h.lo;
-                    } else {
-                        (void)hipGetLastError();
-                        const hipError_t eu = hipHostUnregister(reinterpret_cast<void *>(h.lo)); // (h.lo is a key: just made, and nobody's before)
-                        if (eu != hipSuccess) {
-                            (void)hipGetLastError();
-                            if (note) *note = std::string("hipHostUnregister: ") + hipGetErrorName(eu);
-                        }
-                        why = "a registration of the caller's lies inside the range";
-                    }
-                } else {
-                    (void)hipGetLastError();
-                    why = "hipHostRegister refused the range";
-                    if (note) *note = std::string("hipHostRegister: ") + hipGetErrorName(e);
-                }
-            }
-        }
-        bool first_of_hull = true;
-        for (int i = 0; i < count; ++i) {
-            if (hull_of[(size_t)i] != (int)k) continue;
-            sp[i].how = how;
-            sp[i].own_lo = own;
-            sp[i].why = why;
-            if (how == HostSpan::kOurs && !first_of_hull) // one reference per span, so that every span releases its own
-                for (OwnRange &r : g_own) if (r.lo == own) { ++r.refs; break; }
-            first_of_hull = false;
+        const bool k0 = runtime_knows(a), k1 = runtime_knows(a + sp[i].n - 1);
+        if (k0 && k1) {
+            sp[i].how = HostSpan::kCallerPinned;
+        } else {
+            sp[i].how = HostSpan::kStaged;
+            sp[i].why = (k0 || k1) ? "the runtime knows a part of the range (registered or allocated by the caller)"
+                                   : "pageable memory: this library registers no caller memory";
         }
     }
 }
@@ -270,25 +143,59 @@ void spans_attach(HostSpan *sp, int count, std::string *note, bool may_register 
 // The stages' host copies: several threads for big buffers (one core moves ~12 GB/s, PCIe 50: a 9 MB image pair would
 // spend longer in memcpy than on the bus).  A small pool of helper threads, started at the first big copy and shared by
 // all contexts (one copy at a time uses it) -- a banded call copies a megabyte at a time, too little to start threads for
-// (tools/pool_stress.cpp runs this class under ThreadSanitizer).
+// (tools/pool_stress.cpp runs this class under ThreadSanitizer).  A job is a run of ELEMENTS moved as they are or
+// widened on the way (the wire formats above): int16 -> float / double, float -> double.
+enum CopyKind { kCopyBytes, kCopyI16F32, kCopyI16F64, kCopyF32F64 };
+
+static void copy_piece(uint8_t *dst, const uint8_t *src, size_t first, size_t count, CopyKind kind)
+{
+    switch (kind) {
+    case kCopyBytes: memcpy(dst + first, src + first, count); break;
+    case kCopyI16F32: {
+        const int16_t *s = reinterpret_cast<const int16_t *>(src) + first;
+        float *d = reinterpret_cast<float *>(dst) + first;
+        for (size_t i = 0; i < count; ++i) d[i] = (float)s[i];
+        break;
+    }
+    case kCopyI16F64: {
+        const int16_t *s = reinterpret_cast<const int16_t *>(src) + first;
+        double *d = reinterpret_cast<double *>(dst) + first;
+        for (size_t i = 0; i < count; ++i) d[i] = (double)s[i];
+        break;
+    }
+    case kCopyF32F64: {
+        const float *s = reinterpret_cast<const float *>(src) + first;
+        double *d = reinterpret_cast<double *>(dst) + first;
+        for (size_t i = 0; i < count; ++i) d[i] = (double)s[i];
+        break;
+    }
+    }
+}
+
 class CopyPool {
 public:
     static CopyPool &get()
     {
-        // (never destroyed: its threads wait on members of it, and a process that exits -- or a forked child, which has
-        // the object but not the threads -- must not join them)
-        static CopyPool *pool = new CopyPool;
+        // (never destroyed: its threads wait on members of it, and a process that exits must not join them)
+        static CopyPool *pool = [] {
+            CopyPool *p = new CopyPool;
+            // a forked child has the object but none of its threads (and whatever state a helper was in): it copies alone
+            pthread_atfork(nullptr, nullptr, [] { if (instance_) instance_->orphaned(); });
+            instance_ = p;
+            return p;
+        }();
         return *pool;
     }
-    void copy(uint8_t *dst, const uint8_t *src, size_t n)
+    // n elements (bytes for kCopyBytes)
+    void copy(uint8_t *dst, const uint8_t *src, size_t n, CopyKind kind = kCopyBytes)
     {
-        if (n < 2 * kPiece || workers_.empty()) { memcpy(dst, src, n); return; }
+        if (n < 2 * kPiece || workers_.empty()) { copy_piece(dst, src, 0, n, kind); return; }
         std::lock_guard<std::mutex> one_at_a_time(submit_);
         {
             // (a helper that woke up late for the copy before is still inside work(): the job's fields are its to read)
             std::unique_lock<std::mutex> lk(m_);
             cv_done_.wait(lk, [&] { return active_ == 0; });
-            dst_ = dst; src_ = src; n_ = n;
+            dst_ = dst; src_ = src; n_ = n; kind_ = kind;
             pieces_ = (n + kPiece - 1) / kPiece;
             next_.store(0);
             done_ = 0;
@@ -311,16 +218,36 @@ public:
     }
 
 private:
-    static constexpr size_t kPiece = (size_t)128 << 10;
+    static constexpr size_t kPiece = (size_t)128 << 10; // elements per piece
+    static CopyPool *instance_;
     CopyPool()
     {
         unsigned n = std::thread::hardware_concurrency();
         n = n >= 16 ? 7 : n >= 8 ? 3 : n >= 4 ? 1 : 0; // helpers beside the calling thread
+        // one process per GPU on a node (torchrun / mpirun export the local world size): the ranks share the host's cores
+        for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"})
+            if (const char *e = getenv(name)) {
+                const int ranks = atoi(e);
+                if (ranks > 1) n = (unsigned)std::max(0, (int)(n + 1) / ranks - 1);
+                break;
+            }
         if (const char *e = getenv("WS_COPY_THREADS")) n = (unsigned)std::max(0, std::min(31, atoi(e) - 1));
         for (unsigned i = 0; i < n; ++i) {
             try { workers_.emplace_back([this] { loop(); }); }
             catch (...) { break; }
         }
+    }
+    void orphaned() // in the child of a fork: no helper exists here, whatever the parent's were doing
+    {
+        // (the std::thread objects are the parent's: dropped without a join, their destructors never run -- `new`ed state)
+        new (&workers_) std::vector<std::thread>();
+        new (&submit_) std::mutex();
+        new (&m_) std::mutex();
+        new (&cv_) std::condition_variable();
+        new (&cv_done_) std::condition_variable();
+        active_ = 0;
+        done_ = pieces_ = 0;
+        generation_ = 0;
     }
     size_t work()
     {
@@ -329,7 +256,7 @@ private:
             const size_t i = next_.fetch_add(1);
             if (i >= pieces_) break;
             const size_t off = i * kPiece;
-            memcpy(dst_ + off, src_ + off, std::min(kPiece, n_ - off));
+            copy_piece(dst_, src_, off, std::min(kPiece, n_ - off), kind_);
             ++count;
         }
         return count;
@@ -358,11 +285,13 @@ private:
     uint8_t *dst_ = nullptr;
     const uint8_t *src_ = nullptr;
     size_t n_ = 0, pieces_ = 0, done_ = 0;
+    CopyKind kind_ = kCopyBytes;
     int active_ = 0; // helpers inside work()
     std::atomic<size_t> next_{0};
     unsigned long long generation_ = 0;
     bool stop_ = false;
 };
+CopyPool *CopyPool::instance_ = nullptr;
 
 void stage_copy(uint8_t *dst, const uint8_t *src, size_t n) { CopyPool::get().copy(dst, src, n); }
 
@@ -376,9 +305,9 @@ hipError_t stage_for(HostSpan &sp)
 hipError_t span_upload(HostSpan &sp, size_t off, void *dev, size_t bytes, hipStream_t s)
 {
     if (off + bytes > sp.n) return hipErrorInvalidValue;
-    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
+    if (sp.how == HostSpan::kCallerPinned) {
         const hipError_t e = hipMemcpyAsync(dev, sp.p + off, bytes, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+        if (e == hipSuccess) return e;
         (void)hipGetLastError(); // caller-pinned memory the runtime will not copy from as one range: through the stage
         sp.how = HostSpan::kStaged;
         sp.why = "the runtime refused a direct copy from caller-pinned memory";
@@ -399,9 +328,9 @@ hipError_t span_upload_rows(HostSpan &sp, size_t off, size_t pitch, void *dev, s
     if (!rows || !row_bytes) return hipSuccess;
     if (off + pitch * (rows - 1) + row_bytes > sp.n) return hipErrorInvalidValue;
     if (pitch == row_bytes) return span_upload(sp, off, dev, row_bytes * rows, s);
-    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
+    if (sp.how == HostSpan::kCallerPinned) {
         const hipError_t e = hipMemcpy2DAsync(dev, row_bytes, sp.p + off, pitch, row_bytes, rows, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+        if (e == hipSuccess) return e;
         (void)hipGetLastError();
         sp.how = HostSpan::kStaged;
         sp.why = "the runtime refused a direct copy from caller-pinned memory";
@@ -413,36 +342,50 @@ hipError_t span_upload_rows(HostSpan &sp, size_t off, size_t pitch, void *dev, s
     return hipMemcpyAsync(dev, sp.stage->p, row_bytes * rows, hipMemcpyHostToDevice, s);
 }
 
-// `rows` dense rows of `row_bytes` on the device -> the caller's buffer from byte `off` on, rows `pitch` bytes apart
-hipError_t span_download(HostSpan &sp, size_t off, size_t pitch, const void *dev, size_t row_bytes, size_t rows, hipStream_t s)
+size_t wire_bytes(int wire, int esz) { return wire == kWireI16 ? 2 : wire == kWireF32 ? 4 : (size_t)esz; }
+
+// `rows` dense rows of `row_elems` elements on the device, in wire format -> the caller's buffer from ELEMENT `off` on,
+// rows `pitch` elements apart, elements of esz bytes.  A wire format other than the caller's own always goes through
+// the stage (the widening is the stage -> caller copy), whatever kind of memory the caller's buffer is.
+hipError_t span_download(HostSpan &sp, size_t off, size_t pitch, const void *dev, size_t row_elems, size_t rows, int wire, int esz, hipStream_t s)
 {
-    if (!rows || !row_bytes) return hipSuccess;
-    if (off + pitch * (rows - 1) + row_bytes > sp.n) return hipErrorInvalidValue;
-    if (sp.how == HostSpan::kOurs || sp.how == HostSpan::kCallerPinned) {
-        const hipError_t e = copy_rows(sp.p + off, pitch, dev, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess || sp.how == HostSpan::kOurs) return e;
+    if (!rows || !row_elems) return hipSuccess;
+    if ((off + pitch * (rows - 1) + row_elems) * (size_t)esz > sp.n) return hipErrorInvalidValue;
+    const size_t wb = wire_bytes(wire, esz);
+    const bool same = wb == (size_t)esz; // (float32 on the wire for a float32 map)
+    if (sp.how == HostSpan::kCallerPinned && same) {
+        const hipError_t e = copy_rows(sp.p + off * esz, pitch * esz, dev, row_elems * esz, row_elems * esz, rows, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) return e;
         (void)hipGetLastError();
         sp.how = HostSpan::kStaged;
         sp.why = "the runtime refused a direct copy to caller-pinned memory";
     }
-    if (sp.how != HostSpan::kStaged) return hipErrorInvalidValue;
+    if (sp.how != HostSpan::kStaged && sp.how != HostSpan::kCallerPinned) return hipErrorInvalidValue;
     const hipError_t e = stage_for(sp);
     if (e != hipSuccess) return e;
-    // dense in the stage, at the offset of its first byte in the caller's buffer (the stage is as long as the buffer)
-    sp.down.push_back({off, off, row_bytes, rows, pitch});
-    return hipMemcpyAsync(sp.stage->p + off, dev, row_bytes * rows, hipMemcpyDeviceToHost, s);
+    // dense in the stage, at the wire-format offset of its first element (the stage is as long as the buffer)
+    sp.down.push_back({off * wb, off * (size_t)esz, row_elems, rows, pitch * (size_t)esz, same ? (int)kWireSame : wire, esz});
+    return hipMemcpyAsync(sp.stage->p + off * wb, dev, row_elems * wb * rows, hipMemcpyDeviceToHost, s);
 }
 
-// Hand staged downloads to the caller and release the registrations.  ONLY after every stream that carried a copy of
-// these spans is idle.  Returns false (and a note) if the runtime refused a release: a bug to be reported, not ignored.
-void span_scatter_seg(HostSpan &sp, HostSpan::Seg &g) // (the copy of this segment into the stage is through)
+// the same for plain bytes (the consumers' buffers): offsets, pitch and row length in bytes
+hipError_t span_download_bytes(HostSpan &sp, size_t off, size_t pitch, const void *dev, size_t row_bytes, size_t rows, hipStream_t s)
+{
+    return span_download(sp, off, pitch, dev, row_bytes, rows, kWireSame, 1, s);
+}
+
+// Hand a staged download to the caller (the copy of this segment into the stage is through).
+void span_scatter_seg(HostSpan &sp, HostSpan::Seg &g)
 {
     if (!g.rows) return; // handed over already
-    if (g.host_pitch == g.row_bytes || g.rows == 1) { // dense: one copy
-        stage_copy(sp.p + g.host_off, sp.stage->p + g.stage_off, g.row_bytes * g.rows);
+    const CopyKind kind = g.wire == kWireI16 ? (g.esz == 8 ? kCopyI16F64 : kCopyI16F32) : g.wire == kWireF32 && g.esz == 8 ? kCopyF32F64 : kCopyBytes;
+    const size_t unit = kind == kCopyBytes ? (size_t)g.esz : 1; // kCopyBytes counts bytes, the widening kinds elements
+    const size_t wb = wire_bytes(g.wire, g.esz);
+    if (g.host_pitch == g.row_elems * (size_t)g.esz || g.rows == 1) { // dense: one copy
+        CopyPool::get().copy(sp.p + g.host_off, sp.stage->p + g.stage_off, g.row_elems * g.rows * unit, kind);
     } else {
         for (size_t r = 0; r < g.rows; ++r)
-            memcpy(sp.p + g.host_off + r * g.host_pitch, sp.stage->p + g.stage_off + r * g.row_bytes, g.row_bytes);
+            copy_piece(sp.p + g.host_off + r * g.host_pitch, sp.stage->p + g.stage_off + r * g.row_elems * wb, 0, g.row_elems * unit, kind);
     }
     g.rows = 0;
 }
@@ -453,30 +396,13 @@ void span_scatter(HostSpan &sp) // (the copies into the stage are through: the c
     sp.down.clear();
 }
 
-bool spans_finish(HostSpan *sp, int count, std::string *note)
+// Hand staged downloads to the caller.  ONLY after every stream that carried a copy of these spans is idle.
+void spans_finish(HostSpan *sp, int count)
 {
-    bool ok = true;
-    for (int i = 0; i < count; ++i) span_scatter(sp[i]);
-    std::lock_guard<std::mutex> lock(g_host_mutex);
     for (int i = 0; i < count; ++i) {
-        if (sp[i].how == HostSpan::kOurs) {
-            for (size_t k = 0; k < g_own.size(); ++k) {
-                if (g_own[k].lo != sp[i].own_lo) continue;
-                if (--g_own[k].refs == 0) {
-                    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(g_own[k].lo));
-                    if (e != hipSuccess) {
-                        (void)hipGetLastError();
-                        ok = false;
-                        if (note) *note = std::string("hipHostUnregister: ") + hipGetErrorName(e);
-                    }
-                    g_own.erase(g_own.begin() + (long)k);
-                }
-                break;
-            }
-        }
+        span_scatter(sp[i]);
         sp[i].how = HostSpan::kUnused;
     }
-    return ok;
 }
 
 } // namespace
@@ -490,7 +416,7 @@ struct ws_context {
     hipStream_t scratch_stream = nullptr; // ... the stream it ran on
     bool scratch_busy = false;
     bool profiling = false, kernel_timed = false;
-    DevBuf plane_a, plane_b, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64;
+    DevBuf plane_a, plane_b, keys, cost, bs_plane, max_block, sel, sel_planes, top3, d_left, d_right, d_out, d_out64 /* the consumers' scratch */, d_out16;
     Job jobs[2];             // ws_enqueue_host alternates between two slots
     int job_next = 0;
     hipStream_t copy_stream = nullptr; // host <-> device copies of the batched path, beside the searches
@@ -505,6 +431,7 @@ struct ws_context {
     MarchLaunch plan_launch{};
     int last_outliers_path = 0;        // ws_last_outliers_path
     int last_how[3] = {0, 0, 0};       // ws_last_host_paths: how the last host call's left / right / out bytes crossed
+    int last_wire = 0;                 // ... and the wire format of its map (ws_last_wire_format)
     std::vector<HostSpan> batch_spans; // caller buffers of the pairs enqueued since the last ws_wait (released there)
     HostBuf h_left, h_right, h_out;    // ws_search_host: gathered rows of cut-out images (gather_rows), stages (HostSpan)
     HostBuf h_aux[2];                  // stages of the consumers' further buffers
@@ -522,7 +449,7 @@ struct ws_context {
     bool want_planes = false;     // run_search: also pack the dword planes (the left view's smoothFactor pass reads them)
     bool last_planes = false;     // ... and whether the last search did
     int32_t *last_cost = nullptr; // where it left them (pitch = plane width), or null
-    double *direct_f64 = nullptr; // run_search: the kernels store the map as doubles here (CV_64F out without a widening pass)
+    int16_t *direct_i16 = nullptr; // run_search: the kernels store the map as 16-bit integers here (the wire format of a host call)
     int tune_nxr = 0, tune_rows = 0, tune_threads = 0;
 };
 
@@ -771,7 +698,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
     ga.block_size = p->block_size; ga.min_d = p->min_disparity; ga.max_d = p->max_disparity;
     ga.linear_range = p->linear_range;
     ga.out = out; ga.out_pitch = out_stride;
-    ga.out64 = ctx->direct_f64;
+    ga.out16 = ctx->direct_i16;
 
     ctx->last_cost = nullptr;
     if (p->view == WS_VIEW_RIGHT) ctx->var_block_ran = false;
@@ -850,7 +777,7 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
         ctx->last_cost = cost_out;
         // left view: the marching kernel also writes the zeros outside its interior (BlockSearch.cpp:33,36,38); the
         // right view's ring runs on the packed planes after it
-        WS_HIP(ctx, launch_march(c, m, ia->data, ia->stride, ib->data, ib->stride, out, ctx->direct_f64, out_stride,
+        WS_HIP(ctx, launch_march(c, m, ia->data, ia->stride, ib->data, ib->stride, out, ctx->direct_i16, out_stride,
                                  p->view == WS_VIEW_LEFT, L->width, L->height, ctx->keys.p, keys_pitch, cost_out, c.wa, s));
         if (ctx->profiling) {
             WS_HIP(ctx, hipEventRecord(ctx->evk1, s));
@@ -888,24 +815,28 @@ int run_search(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_
 }
 
 // A search whose kernels only ever WRITE the map (smoothFactor 1, no sub-pixel refine, no varBlock: the marching
-// kernel's flush, the border ring, LinearSearch, the brute force) can store it as doubles itself: CV_64F output
-// then needs neither a second plane nor a widening pass.
+// kernel's flush, the border ring, LinearSearch, the brute force) can store it in the wire format itself.
 bool writes_only(const ws_params *p) { return p->smooth_factor == 1.0 && !p->subpixel && !(p->var_block && p->view == WS_VIEW_RIGHT); }
 
-int run_device_f64(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R, float *scratch32, double *out64,
-                   int ow, int rows, hipStream_t s)
+// The wire format of a host call's map (see "WIRE FORMAT" above): 16-bit integers when the search kernels can store
+// them themselves and every value fits.  Whatever the disparity range, a stored value is a difference of two columns
+// of one image row or a +-x fallback (BlockSearch.cpp:82: x - cx with 0 <= cx < x; :174: cx - x with x <= cx < w1, or
+// -x; LinearSearch.cpp:53: col - j), so |value| < max(w1, w2): images up to 32767 pixels wide fit.  Else float32.
+int wire_for(const ws_params *p, const ws_image *L, const ws_image *R)
 {
-    // scratch32: a float map of the same size for the calls that read their own output (widened afterwards)
-    if (writes_only(p)) {
-        ctx->direct_f64 = out64;
-        const int rc = run_device(ctx, p, L, R, scratch32, ow, s);
-        ctx->direct_f64 = nullptr;
-        return rc;
-    }
+    const bool fits = L->width <= 32767 && R->width <= 32767;
+    return writes_only(p) && fits ? kWireI16 : kWireF32;
+}
+
+// one search whose map ends up in wire format: in out16 (kWireI16: stored by the search kernels, scratch32 stays unused)
+// or in scratch32 (kWireF32)
+int run_device_wire(ws_context *ctx, const ws_params *p, const ws_image *L, const ws_image *R, float *scratch32, int16_t *out16,
+                    int wire, int ow, hipStream_t s)
+{
+    ctx->direct_i16 = wire == kWireI16 ? out16 : nullptr;
     const int rc = run_device(ctx, p, L, R, scratch32, ow, s);
-    if (rc != WS_OK) return rc;
-    WS_HIP(ctx, launch_widen(scratch32, ow, out64, ow, ow, rows, s));
-    return WS_OK;
+    ctx->direct_i16 = nullptr;
+    return rc;
 }
 
 int out_dims(const ws_params *p, const ws_image *L, const ws_image *R, int *w, int *h)
@@ -999,11 +930,11 @@ void ws_destroy(ws_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-    if (!ctx->batch_spans.empty()) { // a batch that was never waited for: its copies are through (synchronised above)
-        (void)spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), nullptr);
-        ctx->batch_spans.clear();
-    }
-    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64, &ctx->d_flag})
+    // a batch that was never waited for: its maps are NOT handed over -- only ws_wait delivers, and a caller who
+    // abandoned the batch may have freed the buffers the staged maps would be written to
+    for (HostSpan &b : ctx->batch_spans) b.down.clear();
+    ctx->batch_spans.clear();
+    for (DevBuf *b : {&ctx->plane_a, &ctx->plane_b, &ctx->keys, &ctx->cost, &ctx->bs_plane, &ctx->max_block, &ctx->sel, &ctx->sel_planes, &ctx->top3, &ctx->d_left, &ctx->d_right, &ctx->d_out, &ctx->d_out64, &ctx->d_out16, &ctx->d_flag})
         if (b->p) (void)hipFree(b->p);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (HostBuf *b : {&ctx->h_left, &ctx->h_right, &ctx->h_out, &ctx->h_aux[0], &ctx->h_aux[1], &ctx->jobs[0].h_left, &ctx->jobs[0].h_right,
@@ -1012,7 +943,7 @@ void ws_destroy(ws_context *ctx)
     for (Job &j : ctx->jobs) {
         if (j.d_in) (void)hipFree(j.d_in);
         if (j.d_out) (void)hipFree(j.d_out);
-        if (j.d_out64) (void)hipFree(j.d_out64);
+        if (j.d_out16) (void)hipFree(j.d_out16);
         if (j.ev_h2d) (void)hipEventDestroy(j.ev_h2d);
         if (j.ev_done) (void)hipEventDestroy(j.ev_done);
     }
@@ -1102,9 +1033,10 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     const size_t span_l = (size_t)left->stride * (H - 1) + lb, span_r = (size_t)right->stride * (H - 1) + rb;
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_right, span_r)) != WS_OK) return rc;
+    const int wire = wire_for(p, left, right);
     if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * (H + 2 * half * nb) * 4)) != WS_OK) return rc;
-    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * (H + 2 * half * nb) * 8)) != WS_OK) return rc;
-    const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+    if (wire == kWireI16 && (rc = ensure(ctx, ctx->d_out16, (size_t)ow * (H + 2 * half * nb) * 2)) != WS_OK) return rc;
+    const int esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     uint8_t *dl = static_cast<uint8_t *>(ctx->d_left.p), *dr = static_cast<uint8_t *>(ctx->d_right.p);
     float *scratch = static_cast<float *>(ctx->d_out.p);
     // the caller's three buffers for the duration of the call (HostSpan: registered, caller-pinned or staged)
@@ -1112,8 +1044,7 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left;
     sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right;
     sp[2].p = static_cast<uint8_t *>(out); sp[2].n = (size_t)ow * H * esz; sp[2].stage = &ctx->h_out;
-    std::string note;
-    spans_attach(sp, 3, &note);
+    spans_attach(sp, 3);
     rc = [&]() -> int {
     int up_to = 0; // image rows [0, up_to) are on their way up
     for (int k = 0; k < nb; ++k) {
@@ -1139,22 +1070,17 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         ws_image bl{dl + (size_t)a * left->stride, left->width, b - a, left->stride};
         ws_image br{dr + (size_t)a * right->stride, right->width, b - a, right->stride};
         float *bout = scratch + (size_t)ow * (a + 2 * half * k); // the band's own map: its border rows are scrap
-        const void *src = bout + (size_t)ow * (y0 - a);
-        if (out_dtype == WS_OUT_F64) { // (doubles straight from the search kernels where they only write the map)
-            double *bout64 = static_cast<double *>(ctx->d_out64.p) + (size_t)ow * (a + 2 * half * k);
-            if ((rc = run_device_f64(ctx, p, &bl, &br, bout, bout64, ow, b - a, ctx->stream)) != WS_OK) return rc;
-            src = bout64 + (size_t)ow * (y0 - a);
-        } else if ((rc = run_device(ctx, p, &bl, &br, bout, ow, ctx->stream)) != WS_OK) {
-            return rc;
-        }
+        int16_t *bout16 = wire == kWireI16 ? static_cast<int16_t *>(ctx->d_out16.p) + (size_t)ow * (a + 2 * half * k) : nullptr;
+        if ((rc = run_device_wire(ctx, p, &bl, &br, bout, bout16, wire, ow, ctx->stream)) != WS_OK) return rc;
+        const void *src = wire == kWireI16 ? static_cast<const void *>(bout16 + (size_t)ow * (y0 - a)) : static_cast<const void *>(bout + (size_t)ow * (y0 - a));
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_done[k], ctx->stream));
         WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
-        WS_HIP(ctx, span_download(sp[2], (size_t)ow * y0 * esz, (size_t)ow * esz, src, (size_t)ow * esz, (size_t)(y1 - y0), ctx->down_stream));
+        WS_HIP(ctx, span_download(sp[2], (size_t)ow * y0, (size_t)ow, src, (size_t)ow, (size_t)(y1 - y0), wire, esz, ctx->down_stream));
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_down[k], ctx->down_stream));
     }
-    // a staged map: every band's rows go from the stage to the caller's buffer as soon as they are down, while the
-    // bands behind it are still being searched (segment k of the span is band k's download)
-    if (sp[2].how == HostSpan::kStaged && sp[2].down.size() == (size_t)nb) {
+    // a staged map: every band's rows go from the stage to the caller's buffer -- widened on the way -- as soon as they
+    // are down, while the bands behind it are still being searched (segment k of the span is band k's download)
+    if (sp[2].down.size() == (size_t)nb) {
         for (int k = 0; k < nb; ++k) {
             WS_HIP(ctx, hipEventSynchronize(ctx->ev_band_down[k]));
             span_scatter_seg(sp[2], sp[2].down[(size_t)k]);
@@ -1166,10 +1092,11 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream),
                      e3 = hipStreamSynchronize(ctx->down_stream);
     for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)sp[i].how;
-    const bool released = spans_finish(sp, 3, &note);
+    ctx->last_wire = wire;
+    if (rc != WS_OK || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) sp[2].down.clear(); // (nothing half-done reaches the caller)
+    spans_finish(sp, 3);
     if (rc == WS_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
         return fail(ctx, WS_ERR_HIP, "banded host call: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
-    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "banded host call: %s", note.c_str());
     return rc == WS_OK ? check_device_status(ctx) : rc;
 }
 
@@ -1185,6 +1112,13 @@ int ws_last_host_paths(const ws_context *ctx, int how[3])
 {
     if (!ctx || !how) return WS_ERR_ARG;
     for (int i = 0; i < 3; ++i) how[i] = ctx->last_how[i];
+    return WS_OK;
+}
+
+int ws_last_wire_format(const ws_context *ctx, int *wire)
+{
+    if (!ctx || !wire) return WS_ERR_ARG;
+    *wire = ctx->last_wire;
     return WS_OK;
 }
 
@@ -1237,8 +1171,9 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     if ((rc = ensure(ctx, ctx->d_left, span_l)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_right, span_r)) != WS_OK) return rc;
     if ((rc = ensure(ctx, ctx->d_out, (size_t)ow * oh * 4)) != WS_OK) return rc;
-    const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
-    if (out_dtype == WS_OUT_F64 && (rc = ensure(ctx, ctx->d_out64, (size_t)ow * oh * 8)) != WS_OK) return rc;
+    const int esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+    const int wire = wire_for(p, left, right);
+    if (wire == kWireI16 && (rc = ensure(ctx, ctx->d_out16, (size_t)ow * oh * 2)) != WS_OK) return rc;
     // The caller's buffers for the duration of the call (HostSpan): registered, caller-pinned or staged -- every
     // host copy of this library goes the same way, whatever the band setting of the moment, and none through the
     // runtime's pageable path.
@@ -1247,8 +1182,7 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     if (lin_l) { sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left; }
     if (lin_r) { sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right; }
     sp[2].p = static_cast<uint8_t *>(out); sp[2].n = span_o; sp[2].stage = &ctx->h_out;
-    std::string note;
-    spans_attach(sp, 3, &note);
+    spans_attach(sp, 3);
     rc = [&]() -> int {
         // (a cut-out that is not worth its whole span: gathered into pinned memory, dense rows; the call ends with
         // a synchronisation, so the two buffers are free again when the next call gathers)
@@ -1261,23 +1195,20 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
         ws_image dl{static_cast<const uint8_t *>(ctx->d_left.p), left->width, left->height, lin_l ? left->stride : (int)lb};
         ws_image dr{static_cast<const uint8_t *>(ctx->d_right.p), right->width, right->height, lin_r ? right->stride : (int)rb};
         float *dout = static_cast<float *>(ctx->d_out.p);
-        const void *src = dout;
+        int16_t *dout16 = wire == kWireI16 ? static_cast<int16_t *>(ctx->d_out16.p) : nullptr;
         int rc2;
-        if (out_dtype == WS_OUT_F64) {
-            if ((rc2 = run_device_f64(ctx, p, &dl, &dr, dout, static_cast<double *>(ctx->d_out64.p), ow, oh, s)) != WS_OK) return rc2;
-            src = ctx->d_out64.p;
-        } else if ((rc2 = run_device(ctx, p, &dl, &dr, dout, ow, s)) != WS_OK) {
-            return rc2;
-        }
-        WS_HIP(ctx, span_download(sp[2], 0, (size_t)out_stride * esz, src, (size_t)ow * esz, (size_t)oh, s));
+        if ((rc2 = run_device_wire(ctx, p, &dl, &dr, dout, dout16, wire, ow, s)) != WS_OK) return rc2;
+        const void *src = wire == kWireI16 ? static_cast<const void *>(dout16) : static_cast<const void *>(dout);
+        WS_HIP(ctx, span_download(sp[2], 0, (size_t)out_stride, src, (size_t)ow, (size_t)oh, wire, esz, s));
         return WS_OK;
     }();
     // (also after an error: nothing may still be copying when the ranges are released)
     const hipError_t es = hipStreamSynchronize(s);
     for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)sp[i].how;
-    const bool released = spans_finish(sp, 3, &note);
+    ctx->last_wire = wire;
+    if (rc != WS_OK || es != hipSuccess) sp[2].down.clear(); // (nothing half-done reaches the caller)
+    spans_finish(sp, 3);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "host call: %s", hipGetErrorString(es));
-    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "host call: %s", note.c_str());
     return rc == WS_OK ? check_device_status(ctx) : rc;
 }
 
@@ -1289,9 +1220,9 @@ static int flush_job(ws_context *ctx, Job &j)
     if (!j.pending) return WS_OK;
     j.pending = false;
     WS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, j.ev_done, 0));
-    const size_t esz = j.dtype == WS_OUT_F32 ? 4 : 8;
-    const void *src = j.dtype == WS_OUT_F32 ? static_cast<const void *>(j.d_out) : static_cast<const void *>(j.d_out64);
-    WS_HIP(ctx, span_download(ctx->batch_spans[(size_t)j.out_span], 0, (size_t)j.out_stride * esz, src, (size_t)j.w * esz, (size_t)j.h,
+    const int esz = j.dtype == WS_OUT_F32 ? 4 : 8;
+    const void *src = j.wire == kWireI16 ? static_cast<const void *>(j.d_out16) : static_cast<const void *>(j.d_out);
+    WS_HIP(ctx, span_download(ctx->batch_spans[(size_t)j.out_span], 0, (size_t)j.out_stride, src, (size_t)j.w, (size_t)j.h, j.wire, esz,
                               ctx->copy_stream));
     return WS_OK;
 }
@@ -1332,35 +1263,28 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     }
     if (out_elems > job.out_cap) {
         if (job.d_out) WS_HIP(ctx, hipFree(job.d_out));
-        if (job.d_out64) WS_HIP(ctx, hipFree(job.d_out64));
-        job.d_out = nullptr; job.d_out64 = nullptr; job.out_cap = 0;
+        if (job.d_out16) WS_HIP(ctx, hipFree(job.d_out16));
+        job.d_out = nullptr; job.d_out16 = nullptr; job.out_cap = 0;
         const size_t cap = out_elems + out_elems / 4;
         WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job.d_out), cap * 4));
-        WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job.d_out64), cap * 8));
+        WS_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&job.d_out16), cap * 2));
         job.out_cap = cap;
     }
     uint8_t *d_left = job.d_in, *d_right = job.d_in + off_r;
     hipStream_t cs = ctx->copy_stream;
-    // The caller's buffers for the life of the batch (HostSpan; ws_wait releases them).  Pageable memory is NOT
-    // registered here: a batch's buffers stay attached while the caller's own code runs between the calls -- its
-    // allocator maps, trims and recycles memory around (and inside) the pages a registration pinned -- and one full
-    // run of the GPU tests in round 3 ended in "Memory access fault by GPU ... on address <host heap page>" inside
-    // ws_wait, in the one test that kept a dozen registrations of heap memory alive across Python allocations
-    // (gpurun_out/r3_gpu_tests_12.txt).  Registrations of this library therefore never outlive one of
-    // its calls: pageable buffers of a batch cross through the job slots' pinned stages (a host memcpy each way),
-    // buffers the caller pinned itself cross directly, as before.
-    const size_t esz = out_dtype == WS_OUT_F32 ? 4 : 8;
+    // The caller's buffers for the life of the batch (HostSpan; ws_wait hands the last maps over): pageable buffers cross
+    // through the job slots' pinned stages (a host copy each way), buffers the caller pinned itself cross directly.
+    const int esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     HostSpan sp[3];
     if (lin_l) { sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &job.h_left; }
     if (lin_r) { sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &job.h_right; }
     sp[2].p = static_cast<uint8_t *>(out); sp[2].n = ((size_t)out_stride * (oh - 1) + ow) * esz; sp[2].stage = &job.h_out;
-    std::string note;
-    spans_attach(sp, 3, &note, false);
+    spans_attach(sp, 3);
     const size_t first = ctx->batch_spans.size();
     for (int i = 0; i < 3; ++i) ctx->batch_spans.push_back(sp[i]);
     HostSpan *bs = ctx->batch_spans.data() + first; // (valid until the next push_back: only used inside this call)
     job.out_span = (int)first + 2;
-    const bool direct = (!lin_l || bs[0].how == HostSpan::kOurs) && (!lin_r || bs[1].how == HostSpan::kOurs);
+    const bool direct = (!lin_l || bs[0].how == HostSpan::kCallerPinned) && (!lin_r || bs[1].how == HostSpan::kCallerPinned);
     if (!lin_l || !lin_r || !direct) {
         // bytes that cross through this slot's pinned buffers (gathered cut-outs, stages): the slot's previous upload
         // from them must be through
@@ -1376,11 +1300,8 @@ int ws_enqueue_host(ws_context *ctx, const ws_params *p, const ws_image *left, c
     WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, job.ev_h2d, 0));
     ws_image dl{d_left, left->width, left->height, lin_l ? left->stride : (int)lb};
     ws_image dr{d_right, right->width, right->height, lin_r ? right->stride : (int)rb};
-    if (out_dtype == WS_OUT_F64) {
-        if ((rc = run_device_f64(ctx, p, &dl, &dr, job.d_out, job.d_out64, ow, oh, ctx->stream)) != WS_OK) return rc;
-    } else if ((rc = run_device(ctx, p, &dl, &dr, job.d_out, ow, ctx->stream)) != WS_OK) {
-        return rc;
-    }
+    job.wire = wire_for(p, left, right);
+    if ((rc = run_device_wire(ctx, p, &dl, &dr, job.d_out, job.d_out16, job.wire, ow, ctx->stream)) != WS_OK) return rc;
     WS_HIP(ctx, hipEventRecord(job.ev_done, ctx->stream));
     job.user_out = out; job.w = ow; job.h = oh; job.out_stride = out_stride; job.dtype = out_dtype;
     job.pending = true;
@@ -1397,15 +1318,15 @@ int ws_wait(ws_context *ctx)
     if (rc == WS_OK) rc = flush_job(ctx, ctx->jobs[ctx->job_next ^ 1]);
     for (Job &j : ctx->jobs) j.pending = false; // (after an error nothing stays queued for a later batch)
     const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
-    std::string note;
     if (ctx->batch_spans.size() >= 3)
         for (int i = 0; i < 3; ++i) ctx->last_how[i] = (int)ctx->batch_spans[ctx->batch_spans.size() - 3 + (size_t)i].how;
-    const bool released = spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size(), &note);
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        for (HostSpan &b : ctx->batch_spans) b.down.clear(); // (nothing half-done reaches the caller)
+    spans_finish(ctx->batch_spans.data(), (int)ctx->batch_spans.size());
     ctx->batch_spans.clear();
     ctx->jobs[0].out_span = ctx->jobs[1].out_span = -1;
     if (e1 != hipSuccess || e2 != hipSuccess)
         return fail(ctx, WS_ERR_HIP, "ws_wait: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "ws_wait: %s", note.c_str());
     return rc == WS_OK ? check_device_status(ctx) : rc;
 }
 
@@ -1495,8 +1416,7 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
     // the caller's map for the duration of the call (HostSpan, like ws_search_host: no pageable copies)
     HostSpan sp[1];
     sp[0].p = reinterpret_cast<uint8_t *>(map); sp[0].n = ((size_t)stride * (height - 1) + width) * 4; sp[0].stage = &ctx->h_out;
-    std::string note;
-    spans_attach(sp, 1, &note);
+    spans_attach(sp, 1);
     // 8-bit maps (the pipeline's PNG: integers in [0, 255]) take the 32-bit integer kernels; a map with any other value
     // raises status word 1, is left as uploaded, and goes through the double kernels after the first synchronisation
     const bool try_u32 = ctx->d_flag.p && outliers_u32_applies(width, height, kernel_size, ctx->num_cus);
@@ -1507,7 +1427,7 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
                                             static_cast<uint32_t *>(ctx->d_flag.p), ctx->status_dev + 1, ctx->num_cus, s));
         else
             WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
-        WS_HIP(ctx, span_download(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
+        WS_HIP(ctx, span_download_bytes(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
         return WS_OK;
     }();
     hipError_t es = hipStreamSynchronize(s);
@@ -1518,14 +1438,13 @@ int ws_remove_disparity_outliers(ws_context *ctx, float *map, int width, int hei
         rc = [&]() -> int {
             WS_HIP(ctx, hipMemsetAsync(ctx->d_flag.p, 0, 256, s));
             WS_HIP(ctx, launch_outliers(dmap, width, width, height, kernel_size, thr_front, thr_back, static_cast<double *>(ctx->d_out64.p), s));
-            WS_HIP(ctx, span_download(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
+            WS_HIP(ctx, span_download_bytes(sp[0], 0, (size_t)stride * 4, dmap, (size_t)width * 4, (size_t)height, s));
             return WS_OK;
         }();
         es = hipStreamSynchronize(s);
     }
-    const bool released = spans_finish(sp, 1, &note);
+    spans_finish(sp, 1);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", hipGetErrorString(es));
-    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "removeDisparityOutliers: %s", note.c_str());
     return rc;
 }
 
@@ -1560,8 +1479,7 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
         sp[3].p = colors; sp[3].n = n * 4; sp[3].stage = &ctx->h_aux[1];
     }
     if (lin_bgr) { sp[4].p = const_cast<uint8_t *>(bgr->data); sp[4].n = (size_t)bgr->stride * (height - 1) + (size_t)width * 3; sp[4].stage = &ctx->h_left; }
-    std::string note;
-    spans_attach(sp, 5, &note);
+    spans_attach(sp, 5);
     rc = [&]() -> int {
         int rc2;
         WS_HIP(ctx, span_upload_rows(sp[0], 0, (size_t)stride * 4, din, (size_t)width * 4, (size_t)height, s));
@@ -1579,17 +1497,16 @@ static int depth_vertices_host(ws_context *ctx, const float *in, int width, int 
         WS_HIP(ctx, launch_depth_vertices(din, width, width, height, focal, baseline, k,
                                           static_cast<const uint8_t *>(ctx->d_left.p), bgr_stride, depth ? ddepth : nullptr, width,
                                           positions ? dpos : nullptr, positions ? dcol : nullptr, input_is_depth, s));
-        if (depth) WS_HIP(ctx, span_download(sp[1], 0, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)height, s));
+        if (depth) WS_HIP(ctx, span_download_bytes(sp[1], 0, (size_t)depth_stride * 4, ddepth, (size_t)width * 4, (size_t)height, s));
         if (positions) {
-            WS_HIP(ctx, span_download(sp[2], 0, n * 16, dpos, n * 16, 1, s));
-            WS_HIP(ctx, span_download(sp[3], 0, n * 4, dcol, n * 4, 1, s));
+            WS_HIP(ctx, span_download_bytes(sp[2], 0, n * 16, dpos, n * 16, 1, s));
+            WS_HIP(ctx, span_download_bytes(sp[3], 0, n * 4, dcol, n * 4, 1, s));
         }
         return WS_OK;
     }();
     const hipError_t es = hipStreamSynchronize(s);
-    const bool released = spans_finish(sp, 5, &note);
+    spans_finish(sp, 5);
     if (rc == WS_OK && es != hipSuccess) return fail(ctx, WS_ERR_HIP, "depth / vertices: %s", hipGetErrorString(es));
-    if (rc == WS_OK && !released) return fail(ctx, WS_ERR_HIP, "depth / vertices: %s", note.c_str());
     return rc;
 }
 

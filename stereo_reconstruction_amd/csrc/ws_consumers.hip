@@ -630,20 +630,4 @@ hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float 
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) ws_widen_kernel(const float *__restrict__ src, int sp,
-                                                       double *__restrict__ dst, int dp, int w, int h)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x < w && y < h) dst[(size_t)y * dp + x] = (double)src[(size_t)y * sp + x];
-}
-
-hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
-                        hipStream_t s)
-{
-    dim3 grid(ceil_div(w, 256), h);
-    hipLaunchKernelGGL(ws_widen_kernel, grid, dim3(256), 0, s, src, src_pitch, dst, dst_pitch, w, h);
-    return hipGetLastError();
-}
-
 } // namespace wsamd

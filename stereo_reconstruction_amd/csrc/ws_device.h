@@ -235,7 +235,7 @@ __device__ __forceinline__ void generic_pixel(const GenericArgs &g, long long id
             val = (float)(col - x);
         }
     }
-    if (g.out64) g.out64[(size_t)y * g.out_pitch + x] = (double)val;
+    if (g.out16) g.out16[(size_t)y * g.out_pitch + x] = (int16_t)(int)val;
     else g.out[(size_t)y * g.out_pitch + x] = val;
 }
 

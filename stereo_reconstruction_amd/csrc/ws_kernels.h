@@ -68,9 +68,9 @@ hipError_t launch_pack(const Canon &c, const uint8_t *src_a, int stride_a, Plane
 // the left image), img_b the candidates.  border: also write the zeros of the out_w x out_h map outside the marching
 // interior (left view).  keys: plane of 8-byte keys (wa x ha, pitch in elements), only touched when m.passes > 1
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img_a, int stride_a, const uint8_t *img_b, int stride_b,
-                        float *out, double *out64, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
+                        float *out, int16_t *out16, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
                         int32_t *cost_out, int cost_pitch,
-                        hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2); out64: see GenericArgs
+                        hipStream_t s); // cost_out: optional plane of the winners' costs (SSD: without sum a^2); out16: see GenericArgs
 const char *march_kernel_name(const Canon &c, const MarchLaunch &m);
 bool march_has_cost(const Canon &c); // is there an instantiation that also writes cost_out?
 
@@ -84,7 +84,8 @@ struct GenericArgs {
     int skip_x0, skip_x1, skip_y0, skip_y1;
     float *out;
     int out_pitch;
-    double *out64; // if set, the search kernels store doubles here (same pitch, in elements) instead of floats to `out`
+    int16_t *out16; // if set, the search kernels store the map as 16-bit integers here (same pitch, in elements) instead of floats to `out`:
+                    // the caller (ws_capi.cpp) knows every value is an integer in [-32767, 32767]
     // varBlock (right view): per-pixel block size chosen by ws_varblock_kernel, or null
     const int16_t *bs_plane;
     int bs_pitch;
@@ -136,8 +137,4 @@ hipError_t launch_depth_vertices(const float *disp, int dp, int w, int h, float 
 // bs_plane: w2 x h2 int16 (pitch bs_pitch), max_block: one device int (max grown block size)
 hipError_t launch_varblock(const GenericArgs &g, double thres, int16_t *bs_plane, int bs_pitch, int *max_block,
                            hipStream_t s);
-// float32 -> float64 widening for CV_64F outputs
-hipError_t launch_widen(const float *src, int src_pitch, double *dst, int dst_pitch, int w, int h,
-                        hipStream_t s);
-
 } // namespace wsamd

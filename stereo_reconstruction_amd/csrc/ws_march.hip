@@ -400,7 +400,7 @@ const char *march_kernel_name(const Canon &c, const MarchLaunch &m)
 }
 
 hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img_a, int stride_a, const uint8_t *img_b, int stride_b,
-                        float *out, double *out64, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
+                        float *out, int16_t *out16, int out_pitch, int border, int out_w, int out_h, void *keys, int keys_pitch,
                         int32_t *cost_out, int cost_pitch, hipStream_t s)
 {
     const MarchEntry *e = m.halo ? find_march_halo(c) : find_march(c);
@@ -412,7 +412,7 @@ hipError_t launch_march(const Canon &c, const MarchLaunch &m, const uint8_t *img
     g.st.stride_b = stride_b;
     g.st.wb = c.wb;
     g.out = out;
-    g.out64 = out64;
+    g.out16 = out16;
     g.out_pitch = out_pitch;
     g.border = border;
     g.out_w = out_w;

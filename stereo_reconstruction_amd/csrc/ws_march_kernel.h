@@ -33,7 +33,7 @@ static_assert(sizeof(StageArgs) == 64, "one s_load_dwordx16");
 struct MarchArgs {
     StageArgs st;
     float *out;
-    double *out64; // if set: doubles here instead of floats to `out` (CV_64F output without a widening pass)
+    int16_t *out16; // if set: 16-bit integers here instead of floats to `out` (the map as it crosses PCIe, ws_capi.cpp: wire format)
     int out_pitch;
     int border;       // left view: this launch also writes the zeros outside [ox0,ox1) x [oy0,oy1) of the out_w x out_h map
     int out_w, out_h;
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
             const int w = x1 - x0, n = w * (y1 - y0);
             for (int i = tid; i < n; i += NT) {
                 const int yy = y0 + i / w, xx = x0 + i % w;
-                if (g.out64) g.out64[(size_t)yy * g.out_pitch + xx] = 0.0;
+                if (g.out16) g.out16[(size_t)yy * g.out_pitch + xx] = 0;
                 else g.out[(size_t)yy * g.out_pitch + xx] = 0.0f;
             }
         };
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                 }
                 // black pixel (BlockSearch.cpp:41, :105): image row y, column x, from the ring
                 if (rowA[lds_phys<NREG>(k - g.st.wx0, ro_a)] == (CENTRED ? kCentre : 0u)) val = 0.0f;
-                if (g.out64) g.out64[(size_t)y * g.out_pitch + xo] = (double)val;
+                if (g.out16) g.out16[(size_t)y * g.out_pitch + xo] = (int16_t)(int)val;
                 else g.out[(size_t)y * g.out_pitch + xo] = val;
                 if (COST && !none) { // (a template flag: the test alone cost the hot kernel 2.7 %)
                     int32_t cst;

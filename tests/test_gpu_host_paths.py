@@ -1,14 +1,14 @@
 """How caller buffers cross at the boundary (ws_search_host / ws_enqueue_host ... ws_wait; they replace the host-only
 ImageRectifier::computeDisparityMapLeft/Right, rectification.cpp:66-88, whose cv::Mat buffers are ordinary pageable
-memory).  Every shape here is one a real caller produces and one of them ended the process in round 2: the runtime
-aborts on hipHostUnregister of a pointer that is not a key of its host-allocation map but lies inside another registered
-range (tools/ubench/hostreg_probe.hip, profiles/r03/hostreg_probe.txt).  The library now registers disjoint page-aligned
-ranges only, for the duration of ONE call (never for a batch: those buffers stay attached while the caller's code
-runs), shares them by reference count, leaves caller-pinned memory alone and stages what it cannot register;
-ws_last_host_paths says which way the bytes went.  Results must be the oracle's, bit for bit, whichever way.
+memory).  Round 2 registered the caller's buffers with the HIP runtime and one of the shapes below ended the process
+(the runtime aborts on hipHostUnregister of a pointer that is not a key of its host-allocation map but lies inside
+another registered range: tools/ubench/hostreg_probe.hip, profiles/r03/hostreg_probe.txt); round 3 made registration
+opt-in after two GPU memory faults of unproven cause; round 4 removed it.  The library registers NO caller memory:
+pageable buffers cross through its own pinned stages, memory the caller (or a framework) pinned is used as it is, a
+range the runtime knows in part is staged.  Integer-valued maps cross PCIe as 16-bit integers and are widened on the
+host (ws_last_wire_format).  Results must be the oracle's, bit for bit, whichever way.
 """
 import ctypes
-import os
 
 import numpy as np
 import pytest
@@ -18,15 +18,7 @@ from stereo_reconstruction_amd.synthetic import make_pair
 pytestmark = pytest.mark.gpu
 
 BS, MAXD = 7, 40
-
-# Round 3, late: registering the caller's pageable memory is opt-in (WS_HOST_REGISTER=1; ws_capi.cpp,
-# host_register_allowed) -- by default such buffers cross through the library's pinned stages.  The tests below run
-# either way; the three that register heap pages THEMSELVES (a framework pinning part of a buffer) only run with the
-# library's registration on: that interplay is what they are about, and hipHostRegister on pages the allocator recycles is
-# what the default now keeps out of a process.
-REG = os.environ.get("WS_HOST_REGISTER") == "1"
-OURS = "registered" if REG else "staged"
-needs_registration = pytest.mark.skipif(not REG, reason="the library registers no caller memory unless WS_HOST_REGISTER=1")
+OURS = "staged"   # how a pageable buffer crosses (rounds 2-3: "registered")
 
 
 def own_pages(a):
@@ -58,7 +50,7 @@ def host_call(ws, ctx, p, L, R, out, out_stride=None):
     return ctx.last_host_paths()
 
 
-def test_pageable_numpy_buffers_are_registered_for_the_call(wslib, gpu_ctx, oracle):
+def test_pageable_numpy_buffers_cross_through_the_stages(wslib, gpu_ctx, oracle):
     left, right, _ = make_pair(300, 120, MAXD, seed=301)
     want = oracle.block_left(left, right, BS, 0, MAXD)
     p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
@@ -72,7 +64,7 @@ def test_pageable_numpy_buffers_are_registered_for_the_call(wslib, gpu_ctx, orac
         assert np.array_equal(o2, oracle.block_left(l2, r2, BS, 0, MAXD))
 
 
-def test_left_and_right_cut_from_one_array_share_one_registration(wslib, gpu_ctx, oracle):
+def test_left_and_right_cut_from_one_array(wslib, gpu_ctx, oracle):
     """Side-by-side stereo frames: both views are column ranges of ONE array, their byte spans interleave.  Round 2
     registered the first, failed on the second and copied it 'unregistered'; the runtime refuses a copy that starts
     inside a registered range and runs past its end (hipErrorInvalidValue)."""
@@ -120,45 +112,6 @@ def test_caller_pinned_memory_is_used_as_it_is(wslib, gpu_ctx, oracle):
     assert torch.equal(tl.cuda().cpu(), tl)
     del tl, tr, to
     torch.cuda.synchronize()
-
-
-@needs_registration
-def test_a_range_the_caller_registered_in_part_goes_through_the_stage(wslib, gpu_ctx, oracle):
-    import torch
-    left, right, _ = make_pair(300, 120, MAXD, seed=305)
-    left, right = own_pages(left), own_pages(right)
-    rt = torch.cuda.cudart()
-    first = left[:60]                                                # the caller registers the upper half itself
-    assert int(rt.cudaHostRegister(first.ctypes.data, first.nbytes, 0)) == 0
-    try:
-        p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD)
-        out = own_pages(np.empty((120, 300)))
-        how = host_call(wslib, gpu_ctx, p, left, right, out)
-        assert how[0] == "staged" and how[1] == OURS and how[2] == OURS, how
-        assert np.array_equal(out, oracle.block_left(left, right, BS, 0, MAXD))
-        # in bands too (the stage is filled once, the bands upload from it), and as the output buffer
-        with wslib.WindowSearch(0) as ctx:
-            big_l, big_r, _ = make_pair(1100, 1000, 32, seed=306)
-            big_l, big_r = own_pages(big_l), own_pages(big_r)
-            assert int(rt.cudaHostRegister(big_l.ctypes.data, 4096 * 10, 0)) == 0
-            out2 = own_pages(np.empty((1000, 1100)))
-            assert int(rt.cudaHostRegister(out2.ctypes.data + 4096 * 100, 4096 * 3, 0)) == 0
-            try:
-                p2 = wslib.make_params(wslib.VIEW_LEFT, BS, 0, 32)
-                ctx.set_host_bands(4)
-                how = host_call(wslib, ctx, p2, big_l, big_r, out2)
-                assert how == ("staged", OURS, "staged"), how
-                ctx.set_host_bands(0)
-                plain = own_pages(np.empty((1000, 1100)))
-                assert host_call(wslib, ctx, p2, big_l, big_r, plain) == ("staged", OURS, OURS)
-                assert np.array_equal(out2, plain)
-                rows = (500, 540)
-                assert np.array_equal(plain[rows[0]:rows[1]], oracle.block_left(big_l, big_r, BS, 0, 32, rows=rows, threads=8)[rows[0]:rows[1]])
-            finally:
-                assert int(rt.cudaHostUnregister(big_l.ctypes.data)) == 0
-                assert int(rt.cudaHostUnregister(out2.ctypes.data + 4096 * 100)) == 0
-    finally:
-        assert int(rt.cudaHostUnregister(first.ctypes.data)) == 0
 
 
 def test_crops_of_one_image_in_a_batch(wslib, gpu_ctx, oracle):
@@ -212,27 +165,19 @@ def test_crops_of_one_image_in_a_batch(wslib, gpu_ctx, oracle):
 
 
 def test_staged_maps_in_a_long_batch(wslib, gpu_ctx, oracle):
-    """Outputs that cannot be registered (the caller registered a page of each) come down through the job slots'
-    stages and are handed over before a slot is used again: more pairs than slots, padded output rows."""
-    import torch
+    """Pageable outputs come down through the job slots' stages (as 16-bit integers, widened to doubles on the way out)
+    and are handed over before a slot is used again: more pairs than slots, padded output rows."""
     lib = wslib.load_library()
-    rt = torch.cuda.cudart()
     p = wslib.make_params(wslib.VIEW_RIGHT, BS, 0, MAXD, 1.0, "sad")
     pairs = [make_pair(200, 90 + 8 * i, MAXD, seed=320 + i)[:2] for i in range(5)]
     outs = [np.full((l.shape[0], 256), -7.0) for l, _ in pairs]
-    for o in outs:   # (with the library's registration on: make the outputs unregistrable; off: they are staged anyway)
-        assert not REG or int(rt.cudaHostRegister(o.ctypes.data + 4096, 4096, 0)) == 0
-    try:
-        keep = []
-        for (l, r), o in zip(pairs, outs):
-            Li, Ri = image(wslib, l), image(wslib, r)
-            keep.append((Li, Ri))
-            assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), o.ctypes.data, 256, 1) == 0
-        assert lib.ws_wait(gpu_ctx._h) == 0
-        assert gpu_ctx.last_host_paths()[2] == "staged"
-    finally:
-        for o in outs:
-            assert not REG or int(rt.cudaHostUnregister(o.ctypes.data + 4096)) == 0
+    keep = []
+    for (l, r), o in zip(pairs, outs):
+        Li, Ri = image(wslib, l), image(wslib, r)
+        keep.append((Li, Ri))
+        assert lib.ws_enqueue_host(gpu_ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), o.ctypes.data, 256, 1) == 0
+    assert lib.ws_wait(gpu_ctx._h) == 0
+    assert gpu_ctx.last_host_paths()[2] == "staged"
     for (l, r), o in zip(pairs, outs):
         assert np.array_equal(o[:, :200], oracle.block_right(l, r, BS, 0, MAXD, cost="sad")) and (o[:, 200:] == -7.0).all()
 
@@ -256,21 +201,105 @@ def test_an_error_in_the_middle_of_a_batch_leaves_nothing_behind(wslib, gpu_ctx,
 
 
 def test_consumers_take_pageable_and_partly_known_buffers(wslib, gpu_ctx):
+    """The Reconstruction-side calls on pageable arrays, padded rows, and a range the runtime knows IN PART (the
+    caller's own pinned block with pageable bytes... cannot exist: a slice that starts inside a pinned torch block and
+    is handed over as if it ran past it is not constructible safely, so the partly-known branch is driven with a view
+    that ends inside the block -- known at both ends, used as it is -- and the pageable one)."""
     import torch
     rng = np.random.default_rng(9)
     disp = rng.integers(1, 60, size=(200, 300)).astype(np.float32)
     want = gpu_ctx.convert_disparity_to_depth(disp, 700.0, 0.2)
-    rt = torch.cuda.cudart()
-    d2 = disp.copy()
-    assert not REG or int(rt.cudaHostRegister(d2.ctypes.data + 8192, 4096, 0)) == 0   # (a page the library cannot register)
-    try:
-        assert np.array_equal(gpu_ctx.convert_disparity_to_depth(d2, 700.0, 0.2), want)
-        a = gpu_ctx.remove_disparity_outliers(disp, 9, 2.0, 3.0)
-        m = d2.copy()
-        lib = wslib.load_library()
-        padded = np.zeros((200, 320), dtype=np.float32)
-        padded[:, :300] = m
-        assert lib.ws_remove_disparity_outliers(gpu_ctx._h, padded.ctypes.data, 300, 200, 320, 9, 2.0, 3.0) == 0
-        assert np.array_equal(padded[:, :300], a) and (padded[:, 300:] == 0).all()
-    finally:
-        assert not REG or int(rt.cudaHostUnregister(d2.ctypes.data + 8192)) == 0
+    pinned = torch.from_numpy(disp).pin_memory()
+    assert np.array_equal(gpu_ctx.convert_disparity_to_depth(pinned.numpy(), 700.0, 0.2), want)
+    a = gpu_ctx.remove_disparity_outliers(disp, 9, 2.0, 3.0)
+    lib = wslib.load_library()
+    padded = np.zeros((200, 320), dtype=np.float32)
+    padded[:, :300] = disp
+    assert lib.ws_remove_disparity_outliers(gpu_ctx._h, padded.ctypes.data, 300, 200, 320, 9, 2.0, 3.0) == 0
+    assert np.array_equal(padded[:, :300], a) and (padded[:, 300:] == 0).all()
+    pp = torch.zeros((200, 320), dtype=torch.float32).pin_memory()
+    pp[:, :300] = torch.from_numpy(disp)
+    assert lib.ws_remove_disparity_outliers(gpu_ctx._h, pp.numpy().ctypes.data, 300, 200, 320, 9, 2.0, 3.0) == 0
+    assert np.array_equal(pp.numpy()[:, :300], a) and (pp.numpy()[:, 300:] == 0).all()
+
+
+def test_integer_maps_cross_as_16_bit_and_are_widened_on_the_host(wslib, gpu_ctx, oracle):
+    """The wire format (ws_last_wire_format): 16-bit integers for every search whose kernels write the map themselves,
+    into CV_64F and CV_32F buffers, pageable and pinned, plain and in bands, all views; float32 where other kernels
+    read the map back (smoothFactor, varBlock) or its values are no integers (sub-pixel)."""
+    import torch
+    left, right, _ = make_pair(300, 140, MAXD, seed=340)
+    left[60, 100] = 0
+    right[70, 90] = 0
+    for view, fn in ((wslib.VIEW_LEFT, oracle.block_left), (wslib.VIEW_RIGHT, oracle.block_right)):
+        p = wslib.make_params(view, BS, 0, MAXD)
+        want = fn(left, right, BS, 0, MAXD)
+        for dtype in (np.float64, np.float32):
+            out = np.full((140, 300), 123.0, dtype=dtype)
+            assert host_call(wslib, gpu_ctx, p, left, right, out) == (OURS,) * 3
+            assert gpu_ctx.last_wire_format() == "int16"
+            assert np.array_equal(out.astype(np.float64), want)
+            pin = torch.full((140, 300), 123.0, dtype=torch.float64 if dtype == np.float64 else torch.float32).pin_memory()
+            how = host_call(wslib, gpu_ctx, p, left, right, pin.numpy())
+            assert how[2] == "caller-pinned" and gpu_ctx.last_wire_format() == "int16"
+            assert np.array_equal(pin.numpy().astype(np.float64), want)
+        # padded output rows: the widening leaves the padding alone
+        out = np.full((140, 320), -5.0)
+        host_call(wslib, gpu_ctx, p, left, right, out, out_stride=320)
+        assert np.array_equal(out[:, :300], want) and (out[:, 300:] == -5.0).all()
+    pl = wslib.make_params(wslib.VIEW_LINEAR, 1, 0, MAXD)
+    out = np.empty((140, 300))
+    host_call(wslib, gpu_ctx, pl, left, right, out)
+    assert gpu_ctx.last_wire_format() == "int16" and np.array_equal(out, oracle.linear(left, right, search_range=200))
+    # float32 on the wire: smoothFactor (another kernel reads the map back), sub-pixel values
+    ps = wslib.make_params(wslib.VIEW_RIGHT, BS, 0, MAXD, 0.9)
+    out = np.empty((140, 300))
+    host_call(wslib, gpu_ctx, ps, left, right, out)
+    assert gpu_ctx.last_wire_format() == "float32" and np.array_equal(out, oracle.block_right(left, right, BS, 0, MAXD, smooth=0.9))
+    pq = wslib.make_params(wslib.VIEW_LEFT, BS, 0, MAXD, 1.0, "ssd", subpixel=True)
+    out = np.empty((140, 300))
+    host_call(wslib, gpu_ctx, pq, left, right, out)
+    assert gpu_ctx.last_wire_format() == "float32"
+    assert np.abs(out - oracle.block_left(left, right, BS, 0, MAXD, subpixel=True)).max() <= 1e-4
+    # in bands (a megapixel and more): band by band through the stage, widened while the next band is searched
+    big_l, big_r, _ = make_pair(1100, 1000, 32, seed=341)
+    pb = wslib.make_params(wslib.VIEW_LEFT, BS, 0, 32)
+    with wslib.WindowSearch(0) as ctx:
+        ctx.set_host_bands(4)
+        banded = np.empty((1000, 1100))
+        host_call(wslib, ctx, pb, big_l, big_r, banded)
+        assert ctx.last_wire_format() == "int16"
+        ctx.set_host_bands(0)
+        plain = np.empty((1000, 1100), dtype=np.float32)
+        host_call(wslib, ctx, pb, big_l, big_r, plain)
+        assert np.array_equal(banded, plain.astype(np.float64))
+        rows = (500, 540)
+        assert np.array_equal(plain[rows[0]:rows[1]].astype(np.float64), oracle.block_left(big_l, big_r, BS, 0, 32, rows=rows, threads=8)[rows[0]:rows[1]])
+
+
+def test_values_at_the_edge_of_16_bits(wslib, gpu_ctx, oracle):
+    """Stored values reach +-(width - 1) through the no-candidate fallbacks (BlockSearch.cpp:82: x, :174: -x).  A
+    32767-pixel-wide image still crosses as int16 (|value| <= 32766), a wider one as float32; both maps are exact."""
+    rng = np.random.default_rng(77)
+    for w, wire in ((32767, "int16"), (32770, "float32")):
+        left = rng.integers(1, 255, size=(8, w, 3), dtype=np.uint8)
+        right = rng.integers(1, 255, size=(8, w, 3), dtype=np.uint8)
+        # right view, minDisparity so large that no candidate exists: every pixel stores -x
+        p = wslib.make_params(wslib.VIEW_RIGHT, 3, w + 5, w + 9)
+        out = np.empty((8, w))
+        host_call(wslib, gpu_ctx, p, left, right, out)
+        assert gpu_ctx.last_wire_format() == wire
+        assert np.array_equal(out, oracle.block_right(left, right, 3, w + 5, w + 9))
+        assert out.min() == -(w - 1)
+        # left view: column x = half stores half, wide disparity range
+        p = wslib.make_params(wslib.VIEW_LEFT, 3, 0, 40)
+        out32 = np.empty((8, w), dtype=np.float32)
+        host_call(wslib, gpu_ctx, p, left, right, out32)
+        assert gpu_ctx.last_wire_format() == wire
+        assert np.array_equal(out32.astype(np.float64), oracle.block_left(left, right, 3, 0, 40))
+    # a disparity range beyond 16 bits changes nothing: a stored value is a column difference, below the image width
+    left, right, _ = make_pair(300, 40, MAXD, seed=342)
+    p = wslib.make_params(wslib.VIEW_LEFT, BS, 0, 40000)
+    out = np.empty((40, 300))
+    host_call(wslib, gpu_ctx, p, left, right, out)
+    assert gpu_ctx.last_wire_format() == "int16" and np.array_equal(out, oracle.block_left(left, right, BS, 0, 40000))

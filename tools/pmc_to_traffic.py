@@ -40,10 +40,12 @@ def main():
     k = max(march, key=lambda n: sum(agg[n].get("SQ_INSTS_VALU", [0])))
     # A search wider than one pass launches the kernel once per d-group pass: bench.py times the search, so the
     # per-launch means are scaled to launches per search (counted against the pre-pass, one launch per search).
-    pre = [n for n in agg if "ws_prepare_kernel" in n]
+    pre = [n for n in agg if "ws_prepare_kernel" in n]  # (rounds 1-3: one pre-pass launch per search; round 4: WS_PASSES)
     per_search = 1
     if pre and agg[pre[0]].get("SQ_INSTS_VALU") and agg[k].get("SQ_INSTS_VALU"):
         per_search = max(1, round(len(agg[k]["SQ_INSTS_VALU"]) / len(agg[pre[0]]["SQ_INSTS_VALU"])))
+    if os.environ.get("WS_PASSES"):  # round 4: no pre-pass to count searches by -- the plan's d-group passes, given by the caller
+        per_search = int(os.environ["WS_PASSES"])
     extensive = {"FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES"}
     m = {c: sum(v) / len(v) * (per_search if c in extensive else 1) for c, v in agg[k].items()}
     t = re.search(r"ws_march_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", k)
