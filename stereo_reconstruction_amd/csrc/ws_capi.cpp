@@ -6,6 +6,9 @@
 #include "ws_kernels.h"
 
 #include <math.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -15,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <fstream>
 #include <mutex>
@@ -52,6 +56,23 @@ struct Job { // one pair in flight on the batched host path
 };
 
 thread_local std::string g_create_error; // ws_last_error(NULL): why the last ws_create on this thread failed
+
+// development knob WS_HOST_TRACE=1: where the host's time goes inside a boundary call (stderr, microseconds since the call began)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    std::string line;
+    HostTrace() : on([] { static const bool v = [] { const char *e = getenv("WS_HOST_TRACE"); return e && atoi(e) == 1; }(); return v; }()), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what, int k = -1)
+    {
+        if (!on) return;
+        char buf[64];
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (k >= 0) snprintf(buf, sizeof buf, " %s%d=%.0f", what, k, us); else snprintf(buf, sizeof buf, " %s=%.0f", what, us);
+        line += buf;
+    }
+    ~HostTrace() { if (on && !line.empty()) fprintf(stderr, "[ws host trace, us]%s\n", line.c_str()); }
+};
 
 // rows of `width_bytes` between buffers with row pitches: one linear copy when both sides are dense
 // (the runtime's 2-D path is slow, very slow for row lengths that are not a multiple of 4 bytes)
@@ -147,25 +168,106 @@ void spans_attach(HostSpan *sp, int count)
 // widened on the way (the wire formats above): int16 -> float / double, float -> double.
 enum CopyKind { kCopyBytes, kCopyI16F32, kCopyI16F64, kCopyF32F64 };
 
+// Streaming forms (AVX2, non-temporal stores) for the copies that WIDEN TO DOUBLES -- the one host copy that writes far
+// more than it reads (config 2, CV_64F: 3 MB of int16 in, 12 MB of doubles out): an ordinary store first reads the line
+// it overwrites.  A/B on one GPU box's host (EPYC 9575F, 8 copy threads, 3 x 30 calls each, profiles/r04/host_trace.txt):
+// the CV_64F call 0.455 -> 0.437 ms with every copy streaming, but the CV_32F call 0.400 -> 0.420 -- the stage copies
+// and the float map are better off in the cache, where the copy engine and the caller find them.  WS_COPY_STREAM=0
+// turns the streaming forms off, =2 applies them to every copy.
+#if defined(__x86_64__)
+#define WS_AVX2 __attribute__((target("avx2")))
+WS_AVX2 static void stream_bytes(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
+    if (n < 256 + head) { memcpy(dst, src, n); return; }
+    memcpy(dst, src, head);
+    size_t i = head;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
+WS_AVX2 static void stream_i16_f64(double *d, const int16_t *s, size_t n)
+{
+    size_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(d + i) & 31); ++i) d[i] = (double)s[i];
+    for (; i + 8 <= n; i += 8) {
+        const __m256i v = _mm256_cvtepi16_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i)));
+        _mm256_stream_pd(d + i, _mm256_cvtepi32_pd(_mm256_castsi256_si128(v)));
+        _mm256_stream_pd(d + i + 4, _mm256_cvtepi32_pd(_mm256_extracti128_si256(v, 1)));
+    }
+    for (; i < n; ++i) d[i] = (double)s[i];
+    _mm_sfence();
+}
+WS_AVX2 static void stream_i16_f32(float *d, const int16_t *s, size_t n)
+{
+    size_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(d + i) & 31); ++i) d[i] = (float)s[i];
+    for (; i + 8 <= n; i += 8)
+        _mm256_stream_ps(d + i, _mm256_cvtepi32_ps(_mm256_cvtepi16_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i *>(s + i)))));
+    for (; i < n; ++i) d[i] = (float)s[i];
+    _mm_sfence();
+}
+WS_AVX2 static void stream_f32_f64(double *d, const float *s, size_t n)
+{
+    size_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(d + i) & 31); ++i) d[i] = (double)s[i];
+    for (; i + 4 <= n; i += 4) _mm256_stream_pd(d + i, _mm256_cvtps_pd(_mm_loadu_ps(s + i)));
+    for (; i < n; ++i) d[i] = (double)s[i];
+    _mm_sfence();
+}
+static int stream_mode() // 0 = never, 1 = the copies that widen to doubles, 2 = every copy
+{
+    static const int v = [] {
+        if (!__builtin_cpu_supports("avx2")) return 0;
+        const char *e = getenv("WS_COPY_STREAM");
+        return e ? std::max(0, std::min(2, atoi(e))) : 1;
+    }();
+    return v;
+}
+#else
+static int stream_mode() { return 0; }
+static void stream_bytes(uint8_t *, const uint8_t *, size_t) {}
+static void stream_i16_f64(double *, const int16_t *, size_t) {}
+static void stream_i16_f32(float *, const int16_t *, size_t) {}
+static void stream_f32_f64(double *, const float *, size_t) {}
+#endif
+
 static void copy_piece(uint8_t *dst, const uint8_t *src, size_t first, size_t count, CopyKind kind)
 {
+    const int sm = stream_mode();
+    const bool fast = count >= 4096 && (sm == 2 || (sm == 1 && (kind == kCopyI16F64 || kind == kCopyF32F64)));
     switch (kind) {
-    case kCopyBytes: memcpy(dst + first, src + first, count); break;
+    case kCopyBytes:
+        if (fast) stream_bytes(dst + first, src + first, count);
+        else memcpy(dst + first, src + first, count);
+        break;
     case kCopyI16F32: {
         const int16_t *s = reinterpret_cast<const int16_t *>(src) + first;
         float *d = reinterpret_cast<float *>(dst) + first;
+        if (fast) { stream_i16_f32(d, s, count); break; }
         for (size_t i = 0; i < count; ++i) d[i] = (float)s[i];
         break;
     }
     case kCopyI16F64: {
         const int16_t *s = reinterpret_cast<const int16_t *>(src) + first;
         double *d = reinterpret_cast<double *>(dst) + first;
+        if (fast) { stream_i16_f64(d, s, count); break; }
         for (size_t i = 0; i < count; ++i) d[i] = (double)s[i];
         break;
     }
     case kCopyF32F64: {
         const float *s = reinterpret_cast<const float *>(src) + first;
         double *d = reinterpret_cast<double *>(dst) + first;
+        if (fast) { stream_f32_f64(d, s, count); break; }
         for (size_t i = 0; i < count; ++i) d[i] = (double)s[i];
         break;
     }
@@ -1044,7 +1146,9 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left;
     sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right;
     sp[2].p = static_cast<uint8_t *>(out); sp[2].n = (size_t)ow * H * esz; sp[2].stage = &ctx->h_out;
+    HostTrace tr;
     spans_attach(sp, 3);
+    tr.mark("attached");
     rc = [&]() -> int {
     int up_to = 0; // image rows [0, up_to) are on their way up
     for (int k = 0; k < nb; ++k) {
@@ -1065,6 +1169,7 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
             WS_HIP(ctx, span_upload(sp[1], orr, dr + orr, nr, ctx->copy_stream));
             up_to = b;
         }
+        tr.mark("up", k);
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_up[k], ctx->copy_stream));
         WS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_band_up[k], 0));
         ws_image bl{dl + (size_t)a * left->stride, left->width, b - a, left->stride};
@@ -1077,13 +1182,17 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
         WS_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, ctx->ev_band_done[k], 0));
         WS_HIP(ctx, span_download(sp[2], (size_t)ow * y0, (size_t)ow, src, (size_t)ow, (size_t)(y1 - y0), wire, esz, ctx->down_stream));
         WS_HIP(ctx, hipEventRecord(ctx->ev_band_down[k], ctx->down_stream));
+        tr.mark("enq", k);
     }
     // a staged map: every band's rows go from the stage to the caller's buffer -- widened on the way -- as soon as they
-    // are down, while the bands behind it are still being searched (segment k of the span is band k's download)
+    // are down, while the bands behind it are still being searched (segment k of the span is band k's download).
+    // (Handing a band over earlier, between two later bands' uploads, measured 3 % slower: profiles/r04/host_trace.txt.)
     if (sp[2].down.size() == (size_t)nb) {
         for (int k = 0; k < nb; ++k) {
             WS_HIP(ctx, hipEventSynchronize(ctx->ev_band_down[k]));
+            tr.mark("down", k);
             span_scatter_seg(sp[2], sp[2].down[(size_t)k]);
+            tr.mark("out", k);
         }
     }
     return WS_OK;
