@@ -41,7 +41,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r03"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
+PROFILE_ROUND = "r04"  # profiles/<round>/traffic_<workload>.json: PMC figures of the committed kernels
+# the marching kernel's sources: a PMC summary is only replayed into the bench line for the build it was taken from
+KERNEL_SOURCES = ["ws_march_kernel.h", "ws_march.hip", "ws_march_nd4.hip", "ws_device.h", "ws_kernels.h"]
+
+
+def kernel_sources_sha1():
+    import hashlib
+    h = hashlib.sha1()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "stereo_reconstruction_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 # A step is one pass of the hot path over one BATCH of pairs of the workload's shape (distinct images, all resident
 # in HBM: 10.6 GB at config 2), sized so that a step is ~0.1 s: the 20 steps the driver times after 5 of warm-up are
@@ -295,6 +306,12 @@ def main():
     summary = {"rank": rank, "pairs": list(mine)[:len(sampled)], "kernel_ms_sum": round(sum(kernel_ms), 4),
                "alg_bytes": sum(alg_bytes), "hyps": float(sum(rows * w * max_d for rows, (w, h, _) in zip(rows_of, todo))),
                "items": len(pairs), "wall_ms": round(own_elapsed * 1e3, 3),
+               # which device this rank is bound to, what the library sees, which host: a straggler is traced from here
+               "device": None if dry else {"local_rank": local_rank, "ws_device_count": ws.device_count(),
+                                           "name": torch.cuda.get_device_name(local_rank), "host": os.uname().nodename,
+                                           "copy_threads_env": os.environ.get("WS_COPY_THREADS"), "local_world_size": os.environ.get("LOCAL_WORLD_SIZE")},
+               # config 4: the row bands this rank searched, (pair, first row, last row + 1)
+               "bands": [[int(items[j][0]), int(items[j][1]), int(items[j][2])] for j in mine] if batch else None,
                "map_hyps": float(sum((y1 - y0) * w * max_d for (w, h, _), (y0, y1) in zip(todo, bands)))}
     if dist is not None:
         summaries = [None] * world
@@ -315,7 +332,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_%s.json" % args.workload)
         if os.path.exists(tfile) and k_ms > 0:
             tj = json.load(open(tfile))
-            if tj.get("kernel") == info["kernel"]:
+            # replayed only for the kernel that ran AND the sources it was profiled from (tools/pmc.sh records their hash)
+            if tj.get("kernel") == info["kernel"] and tj.get("kernel_sources_sha1") == kernel_sources_sha1():
                 traffic = tj["hbm_bytes_per_launch"]
                 if "sq_insts_valu" in tj:
                     # the bound that actually applies: VALU instruction issue
@@ -352,8 +370,11 @@ def main():
             # peak / frac are the HBM figures the contract asks for: algorithmic bytes per launch / kernel time
             "roofline": {"bound": "valu_issue", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_from_profiles": None if traffic is None else "profiles/%s/traffic_%s.json (rocprofv3 --pmc passes of the "
-                                                  "committed kernels, not collected in this run)" % (PROFILE_ROUND, args.workload),
+                         "traffic_from_profiles": ("none: no PMC summary under profiles/%s/ for this kernel and these kernel sources"
+                                                   % PROFILE_ROUND) if traffic is None else
+                                                  "profiles/%s/traffic_%s.json (rocprofv3 --pmc passes of this kernel built from these "
+                                                  "sources -- kernel symbol and source hash match --, not collected in this run)"
+                                                  % (PROFILE_ROUND, args.workload),
                          "kernel": info["kernel"], "kernel_ms": round(k_ms / n_launch, 4),
                          "kernel_ms_in_flight": None if kernel_ms_in_flight is None else round(kernel_ms_in_flight, 4),
                          "launches": n_launch, "algorithmic_bytes": k_bytes / n_launch, "valu_issue_from_profiles": valu,
@@ -368,7 +389,8 @@ def main():
                                   "(--in-flight 1 semantics; BENCH_r01 timed this way), after the timed region as warm-up"}
         if batch or world > 1:
             out["per_rank"] = [{"rank": s["rank"], "items": s["items"], "kernel_ms_sum": s["kernel_ms_sum"],
-                                "wall_ms": s["wall_ms"], "Mdisp_map": round(s["map_hyps"] / 1e6, 1)} for s in summaries]
+                                "wall_ms": s["wall_ms"], "Mdisp_map": round(s["map_hyps"] / 1e6, 1),
+                                "device": s.get("device"), "bands": s.get("bands")} for s in summaries]
 
     single = rank == 0 and world == 1 and not dry
     left, right = host_pairs[0] if host_pairs else (None, None)

@@ -157,6 +157,11 @@ def load_library(build_if_missing=False):
     return lib
 
 
+def device_count():
+    """ws_device_count: the HIP devices this process sees (0 without one; never raises)."""
+    return int(load_library().ws_device_count())
+
+
 def make_params(view, block_size=7, min_disparity=0, max_disparity=64, smooth_factor=1.0,
                 cost="ssd", var_block=False, thres=19.0, subpixel=False, linear_range=200):
     p = _Params()

@@ -744,7 +744,7 @@ int run_device_on(ws_context *ctx, const ws_params *p, const ws_image *L, const 
         ga.block_size = p->block_size; ga.min_d = 0; ga.max_d = p->max_disparity;
         ga.out = out; ga.out_pitch = out_stride;
         // per pixel the best candidate's cost (0 <= s <= 1) or the three best candidates
-        if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height))) != WS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->top3, smooth_left_top_bytes(L->width, L->height, p->smooth_factor))) != WS_OK) return rc;
         uint32_t *top3 = static_cast<uint32_t *>(ctx->top3.p);
         WS_HIP(ctx, launch_smooth_left(ga, p->smooth_factor, top3, ctx->last_march && ctx->last_planes ? &ctx->last_canon : nullptr,
                                        ctx->last_pa, ctx->last_pb, ctx->status_dev, s));

@@ -104,11 +104,11 @@ hipError_t launch_refine_planes(const Canon &c, const MarchLaunch &m, Plane a, P
 // rows the sel plane must be allocated with (whole LDS chunks are copied)
 int smooth_sel_rows(int rows);
 // smoothFactor in [0,1], left view: g.out holds the smoothFactor-1 result on entry
-// top3: smooth_left_top_bytes(w1, h1) of scratch, only read / written when s is outside [0,1]
+// top3: smooth_left_top_bytes(w1, h1, s) of scratch (the row-sum volume at its end only for s outside [0,1])
 // gave_up: host-visible word (device pointer) a band of the raster pass sets when it gave up waiting (the map is then invalid)
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,
                               unsigned int *gave_up, hipStream_t st);
-size_t smooth_left_top_bytes(int w, int h);
+size_t smooth_left_top_bytes(int w, int h, double s);
 // bytes of the bit-plane scratch launch_smooth wants for a w x h map
 size_t smooth_planes_bytes(int w, int h);
 // canon / pa / pb: the right view's canonical search and packed planes when the marching kernel ran

@@ -1189,9 +1189,12 @@ static size_t smooth_left_sync_bytes(int w, int h) { return 64 + ((size_t)h / kB
 
 // (+ the row sums of one slab of disparities, for the factors outside [0, 1])
 static size_t smooth_left_vol_bytes(int w, int h) { return (size_t)kTopSlab * w * h * sizeof(uint32_t); }
-size_t smooth_left_top_bytes(int w, int h)
+// (the volume last, and only for the factors that run the separable top-3 pass: the pipeline's 0.9 does not, and the
+// volume is two thirds more scratch -- 265 MB at 3840 x 2160)
+size_t smooth_left_top_bytes(int w, int h, double s)
 {
-    return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h) + smooth_left_vol_bytes(w, h);
+    const bool outside = !(s >= 0.0 && s <= 1.0);
+    return (size_t)w * h * kTopWords * sizeof(uint32_t) + smooth_left_sync_bytes(w, h) + (outside ? smooth_left_vol_bytes(w, h) : 0);
 }
 
 hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, const Canon *canon, Plane pa, Plane pb,

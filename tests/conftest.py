@@ -33,6 +33,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_core_post_mortem():
+    """A "Memory access fault by GPU" leaves `gpucore.<pid>` in the working directory and takes the process with it, so
+    nothing of THAT run can look at it (round 3 lost gpucore.919 that way).  The next session on the same tree does:
+    every dump found is opened with rocgdb in batch mode -- agents, queues, dispatches, the faulting wave's threads and
+    backtraces -- and the text kept under gpurun_out/ (tools/gpu_session.sh does the same right after a run it wrapped)."""
+    import shutil
+    import subprocess
+    rocgdb = shutil.which("rocgdb") or "/opt/rocm/bin/rocgdb"
+    for core in sorted(glob.glob(os.path.join(ROOT, "gpucore.*")) + glob.glob(os.path.join(os.getcwd(), "gpucore.*"))):
+        if core.endswith(".seen") or not os.path.exists(rocgdb):
+            continue
+        out = os.path.join(ROOT, "gpurun_out", os.path.basename(core) + ".rocgdb.txt")
+        try:
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            r = subprocess.run([rocgdb, "-batch", "-ex", "core-file " + core, "-ex", "info agents", "-ex", "info queues",
+                                "-ex", "info dispatches", "-ex", "info threads", "-ex", "thread apply all bt 4", sys.executable],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=180)
+            with open(out, "w") as f:
+                f.write("# %s (%d bytes), found at the start of a test session\n%s" % (core, os.path.getsize(core), r.stdout[-40000:]))
+            os.rename(core, core + ".seen")
+            sys.__stderr__.write("conftest: GPU core dump %s -> %s\n" % (core, out))
+        except (OSError, subprocess.SubprocessError):
+            pass
+
+
+def pytest_sessionstart(session):
+    if glob.glob(os.path.join(ROOT, "gpucore.*")) or glob.glob(os.path.join(os.getcwd(), "gpucore.*")):
+        _gpu_core_post_mortem()
+
+
 def _amd_log_tail(lines=25):
     for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "amd_runtime_errors_%d.txt*" % os.getpid()))):
         try:

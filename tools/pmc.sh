@@ -4,6 +4,7 @@ set -e
 name=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
+(cd $GRAFT_REPO_ROOT && python3 -c "import bench; print(bench.kernel_sources_sha1())") > $out/kernel_sources.sha1
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \

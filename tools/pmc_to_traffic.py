@@ -60,8 +60,10 @@ def main():
         rates = [float(x) for x in re.findall(r"march-mix \w+\s+waves/SIMD=\d+ :.*?([\d.]+) Tlane-op/s", open(ubench).read())]
         if rates:
             peak, peak_src = max(rates) * 1e12, "best sustained rate of the marching step's own instruction mix in %s" % ubench
+    sha_file = os.path.join(pmc_dir, "kernel_sources.sha1")  # written on the GPU box by tools/pmc.sh
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
     out = {
-        "workload": workload, "kernel": name, "kernel_symbol": k[:120], "launches_per_search": per_search,
+        "workload": workload, "kernel": name, "kernel_sources_sha1": sha, "kernel_symbol": k[:120], "launches_per_search": per_search,
         "source": "%s (rocprofv3 --pmc, FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; tools/pmc_to_traffic.py)" % pmc_dir,
         "fetch_size_kb": m.get("FETCH_SIZE"), "write_size_kb": m.get("WRITE_SIZE"),
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads -> doubled "
