@@ -10,6 +10,12 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <algorithm>
+#include <pthread.h>
+#include <unistd.h>
+#include <sys/wait.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 //@POOL@
 int main()
 {
@@ -29,6 +35,37 @@ int main()
         if (memcmp(a.data(), b.data(), N)) { printf("MISMATCH2\n"); return 1; }
     }
     t.join();
+    // the widening copies (the wire formats of ws_search_host): int16 -> double / float, float -> double
+    {
+        const size_t M = (3 << 20) + 77;
+        std::vector<int16_t> w(M);
+        std::vector<double> d64(M + 3);
+        std::vector<float> f32(M + 3);
+        for (size_t i = 0; i < M; ++i) w[i] = (int16_t)((i * 2654435761u) >> 16);
+        for (int it = 0; it < 20; ++it) {
+            CopyPool::get().copy(reinterpret_cast<uint8_t *>(d64.data() + (it & 3)), reinterpret_cast<const uint8_t *>(w.data()), M - (it & 3), kCopyI16F64);
+            CopyPool::get().copy(reinterpret_cast<uint8_t *>(f32.data() + (it & 1)), reinterpret_cast<const uint8_t *>(w.data()), M - 8, kCopyI16F32);
+            for (size_t i = 0; i < M - 8; i += 1 + i / 64) {
+                if (d64[i + (it & 3)] != (double)w[i] || f32[i + (it & 1)] != (float)w[i]) { printf("WIDEN MISMATCH at %zu\n", i); return 1; }
+            }
+            CopyPool::get().copy(reinterpret_cast<uint8_t *>(d64.data()), reinterpret_cast<const uint8_t *>(f32.data()), M, kCopyF32F64);
+            for (size_t i = 0; i < M; i += 997) if (d64[i] != (double)f32[i]) { printf("F32->F64 MISMATCH\n"); return 1; }
+        }
+    }
+    // a forked child has the pool object but none of its threads: it must copy alone, not wait for helpers
+    {
+        std::thread busy([&] { for (int it = 0; it < 50; ++it) CopyPool::get().copy(d.data(), c.data(), N); });
+        const pid_t pid = fork();
+        if (pid == 0) {
+            alarm(20); // (a child that waits for the parent's helpers would hang: the alarm ends it with a signal)
+            CopyPool::get().copy(b.data(), a.data(), N);
+            _exit(memcmp(a.data(), b.data(), N) ? 3 : 0);
+        }
+        int status = 0;
+        waitpid(pid, &status, 0);
+        busy.join();
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { printf("FORKED CHILD FAILED (status %d)\n", status); return 1; }
+    }
     printf("ok\n");
     return 0;
 }
