@@ -1015,6 +1015,7 @@ int ws_create(int device, ws_context **out)
         return WS_ERR_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    march_set_num_cus(ctx->num_cus);
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&ctx->status_host), 64, hipHostMallocMapped)) != hipSuccess ||
         (e = hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->status_host, 0)) != hipSuccess) {
         fail(nullptr, WS_ERR_HIP, "ws_create: %s", hipGetErrorString(e));

@@ -54,6 +54,8 @@ struct MarchLaunch {
 bool march_supported(const Canon &c);
 // 1 if this SSD window needs centred (byte - 128) planes to keep its sums in 32 bits
 int march_centred(const Canon &c);
+// The CU count the thread-shape rule (march_shape) plans for; ws_create passes its device's.
+void march_set_num_cus(int n);
 // Fill the tiling for this problem (tuning values of 0 = automatic).
 bool march_plan(const Canon &c, int num_cus, int tune_nxr, int tune_strip_rows, int tune_threads,
                 MarchLaunch *out);

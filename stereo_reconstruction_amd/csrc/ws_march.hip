@@ -70,11 +70,15 @@ static int min_chunks(MarchShape s) { return s.x > 8 ? s.x : 8; } // (the flush 
 // a shape with more than 8 columns per thread would keep 4 x-runs with 128 chunks
 static int max_chunks(MarchShape s) { return s.x > 8 ? kMaxT / kMinXRuns : kMaxChunks; }
 
-// Row times a search would take with a thread shape, in units of one row step of the 8 x 8 kernel, on a chip of 256
-// CUs with one workgroup per CU at a time -- the strip planner's own model (march_plan): the chip works through
+// Row times a search would take with a thread shape, in units of one row step of the 8 x 8 kernel, on a chip of
+// g_model_cus CUs with one workgroup per CU at a time -- the strip planner's own model (march_plan): the chip works through
 // ceil(workgroups / CUs) rounds of strips, a strip of R rows costs R + (wh - 1) / 2 + 3 row steps.  A row step of the
 // 8 x 4 kernel covers half the hypotheses per workgroup and costs 0.62 of an 8 x 8 one (measured: 1.19 .. 1.29 times the
 // time per hypothesis over windows 5 .. 17 at D = 512, profiles/r03/nd_grid.txt).
+// the chip the thread-shape rule plans for: the first context's device (ws_create), 256 CUs without one (ws_plan)
+static int g_model_cus = 256;
+void march_set_num_cus(int n) { if (n > 0) g_model_cus = n; }
+
 static double march_model_cost(const Canon &c, MarchShape sh)
 {
     const int dcount = c.d_hi - c.d_lo + 1, out_w = c.ox1 - c.ox0, out_h = c.oy1 - c.oy0;
@@ -90,7 +94,7 @@ static double march_model_cost(const Canon &c, MarchShape sh)
     for (int sc = 1; sc <= out_h; ++sc) {
         const int rows = ceil_div(out_h, sc), st = ceil_div(out_h, rows);
         if (st != sc) continue;
-        const double cost = ceil_div(tiles * st, 256) * (rows + 0.5 * (c.wh - 1) + 3.0);
+        const double cost = ceil_div(tiles * st, g_model_cus) * (rows + 0.5 * (c.wh - 1) + 3.0);
         if (sc == 1 || cost < best) best = cost;
     }
     return best * passes * (same_shape(sh, kShapeNarrow) ? 0.62 : 1.0);
@@ -124,7 +128,7 @@ static MarchShape march_shape(const Canon &c)
     struct Memo { int key[9]; MarchShape shape; };
     thread_local Memo memo[4] = {};
     thread_local int next = 0;
-    const int key[9] = {c.ox1 - c.ox0, c.oy1 - c.oy0, c.d_hi - c.d_lo + 1, c.ww, c.wh, c.ssd, 1, 0, 0};
+    const int key[9] = {c.ox1 - c.ox0, c.oy1 - c.oy0, c.d_hi - c.d_lo + 1, c.ww, c.wh, c.ssd, 1, g_model_cus, 0};
     for (const Memo &m : memo)
         if (!memcmp(m.key, key, sizeof key)) return m.shape;
     const MarchShape sh = march_model_cost(c, kShapeNarrow) < march_model_cost(c, kShapeWide) ? kShapeNarrow : kShapeWide;

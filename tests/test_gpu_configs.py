@@ -165,3 +165,55 @@ def test_motorcycle_e_shaped_unequal_pair(wslib, gpu_ctx, oracle):
         assert np.array_equal(gl[y0:y1], oracle.block_left(right, left, 7, 0, maxd, cost="sad", rows=(y0, y1), threads=8)[y0:y1])
     for y0, y1 in [(0, 2), (h1 // 2, h1 // 2 + 2), (h1 - 2, h1)]:
         assert np.array_equal(gr[y0:y1], oracle.block_right(right, left, 7, 0, maxd, cost="sad", rows=(y0, y1), threads=8)[y0:y1])
+
+
+@pytest.mark.parametrize("cfg", [("config2", 1500, 1000, 7, "ssd", 256, 2), ("config3", 2964, 1988, 9, "sad", 512, 3),
+                                 ("config5", 3840, 2160, 9, "ssd", 1024, 5)])
+def test_the_planners_plan_is_within_5_percent_of_the_best_forced_one(wslib, cfg):
+    """The tiling plan is a pile of constants fitted on one box (march_plan: strip model, 256- vs 512-thread workgroups,
+    halo-exchange tiles).  This replaces the by-hand check of round 3 (profiles/r03/nd_rule_check.txt): the automatic
+    plan against the forced alternatives ws_set_tuning can ask for -- workgroup size 256 / 512 x tile widths 4 / 8 / 16
+    x-runs (8 and 16: the halo-exchange kernels where they exist) -- device-resident, best of three timings each.
+    All plans must give the SAME map."""
+    import torch
+    name, w, h, bs, cost, maxd, seed = cfg
+    left, right, _ = make_pair(w, h, maxd, seed)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    out = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    p = wslib.make_params(wslib.VIEW_LEFT, bs, 0, maxd, 1.0, cost)
+    st = torch.cuda.current_stream().cuda_stream
+    reps = 8 if name == "config2" else 3
+
+    def timed(ctx):
+        for _ in range(2):
+            ctx.search_device(p, tl, tr, out, st)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            ctx.timer_begin(st)
+            for _ in range(reps):
+                ctx.search_device(p, tl, tr, out, st)
+            best = min(best, ctx.timer_end(st) / reps)
+        return best, out.clone()
+
+    with wslib.WindowSearch(0) as ctx:
+        timed(ctx)                                # (clocks up, code loaded: the first timing of a process runs 5-8 % long)
+        auto_ms, auto_map = timed(ctx)
+        auto_plan = ctx.last_launch()
+        results = {}
+        for threads in (256, 512):
+            for nxr in (0, 4, 8, 16):
+                try:
+                    ctx.set_tuning(nxr, 0, threads)
+                    ms, m = timed(ctx)
+                except wslib.WsError:
+                    continue                      # (a tuning the planner cannot satisfy)
+                assert torch.equal(m, auto_map), (name, threads, nxr)
+                results[(threads, nxr)] = (ms, ctx.last_launch()["kernel"])
+        ctx.set_tuning(0, 0, 0)
+        auto_ms = min(auto_ms, timed(ctx)[0])     # (and once more after the others: the box's drift is not the planner's)
+    best_key = min(results, key=lambda k: results[k][0])
+    best_ms = results[best_key][0]
+    print("%s: auto %.4f ms (%s, %d threads); best forced %.4f ms %s %s" % (name, auto_ms, auto_plan["kernel"], auto_plan["threads"],
+                                                                            best_ms, best_key, results[best_key][1]))
+    assert auto_ms <= 1.05 * best_ms, (name, auto_ms, auto_plan, {k: round(v[0], 4) for k, v in results.items()})
