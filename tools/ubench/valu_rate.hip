@@ -14,7 +14,9 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, int iters, uint32_t seed
     uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x5bd1e995u;
     uint32_t acc[CHAINS];
 #pragma unroll
-    for (int c = 0; c < CHAINS; ++c) acc[c] = c + seed;
+    // (per-lane values: with uniform ones the compiler runs the loops that never touch a or b -- lshl_add, add3, sub -- on the
+    // SCALAR unit, and round 3's "12 cycles per v_lshl_add, 8 per v_add3" were 192 / 130 s_lshl + s_add per 64 updates)
+    for (int c = 0; c < CHAINS; ++c) acc[c] = c + seed + a * (uint32_t)(2 * c + 1);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -22,12 +24,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, int iters, uint32_t seed
             for (int c = 0; c < CHAINS; ++c) {
                 if (OP == 0) acc[c] = __builtin_amdgcn_sad_u8(a, b + c, acc[c]);
                 if (OP == 1) acc[c] = __builtin_amdgcn_udot4(a, b + c, acc[c], false);
-                if (OP == 2) acc[c] = (acc[c] << 3) + acc[(c + 1) % CHAINS];          // v_lshl_add_u32 (operands from the other chains: nothing folds)
+                if (OP == 2) asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(acc[c]) : "v"(acc[c]), "v"(acc[(c + 1) % CHAINS])); // (spelled out: the compiler splits some into v_lshlrev + v_add)
                 if (OP == 3) acc[c] = min((int)acc[c], (int)(a + c)) + 1; // v_min + v_add
                 if (OP == 4) acc[c] = acc[c] - acc[(c + 1) % CHAINS];           // v_sub
                 if (OP == 5) acc[c] = __builtin_fmaf(__uint_as_float(acc[c]), 1.0001f, 0.5f); // v_fma_f32
                 if (OP == 6) acc[c] = (uint32_t)min(min((int)acc[c] + 0, (int)acc[(c + 1) % CHAINS] ^ (int)a), (int)acc[(c + 2) % CHAINS]); // v_xor + v_min3_i32
-                if (OP == 7) acc[c] = acc[c] + acc[(c + 1) % CHAINS] + acc[(c + 2) % CHAINS];       // v_add3_u32
+                if (OP == 7) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(acc[c]) : "v"(acc[c]), "v"(acc[(c + 1) % CHAINS]), "v"(acc[(c + 2) % CHAINS]));
                 if (OP == 8) acc[c] = (uint32_t)__builtin_amdgcn_sdot4((int)a, (int)(b + c), (int)acc[c], false); // v_dot4_i32_i8
                 if (OP == 9) { // v_pk_add_u16
                     u16x2 x = __builtin_bit_cast(u16x2, acc[c]), y = __builtin_bit_cast(u16x2, acc[(c + 1) % CHAINS]);
