@@ -336,7 +336,7 @@ def main():
             if tj.get("kernel") == info["kernel"] and tj.get("kernel_sources_sha1") == kernel_sources_sha1():
                 traffic = tj["hbm_bytes_per_launch"]
                 if "sq_insts_valu" in tj:
-                    # the bound that actually applies: VALU instruction issue (DESIGN.md 3.4)
+                    # the bound that actually applies: VALU instruction issue (DESIGN.md 4.5)
                     lane_ops = tj["sq_insts_valu"] * 64.0
                     per_launch_ms = k_ms / n_launch
                     valu = {"from_profiles": True, "lane_ops_per_launch": lane_ops,

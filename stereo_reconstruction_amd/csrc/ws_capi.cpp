@@ -100,7 +100,7 @@ hipError_t host_ensure(HostBuf &b, size_t bytes)
 // the caller's buffers for the duration of a call; round 3 found what that costs inside somebody else's process -- the
 // runtime abort()s on an unregister of a pointer that lies inside another live registration (rocclr device.cpp:373,
 // tools/ubench/hostreg_probe.hip, profiles/r03/hostreg_probe.txt), and two full test runs ended in a GPU memory fault on
-// a host heap page whose cause was never proven (DESIGN.md 3.5) -- and made it opt-in; round 4 removed it: the 16-bit
+// a host heap page whose cause was never proven (DESIGN.md 5) -- and made it opt-in; round 4 removed it: the 16-bit
 // wire format below wins back more than the registration saved.  How bytes cross now:
 //   * pageable memory (a cv::Mat, a numpy array) crosses through pinned staging memory of the library's own
 //     (hipHostMalloc): one host copy each way, on a small pool of threads, band by band beside the transfers;
@@ -591,7 +591,7 @@ int ensure(ws_context *ctx, DevBuf &b, size_t bytes)
 // A narrow cut-out of a much wider image goes through a pinned buffer of the library's own: the rows are gathered
 // on the host and cross as one dense linear copy.  (The runtime's 2-D copy from pageable memory takes a per-row
 // path, ~15 us a row; and no copy of this library reads or writes pageable memory through the runtime any more,
-// see DESIGN.md 3.5.)
+// see DESIGN.md 5.)
 hipError_t gather_rows(HostBuf &b, const ws_image *im)
 {
     const size_t rb = (size_t)im->width * 3;

@@ -1,6 +1,6 @@
 // Probe (GPU box): what hipHostRegister / hipHostUnregister and the runtime's pageable copy path really do on this
 // platform, and which combinations of the two end a process.  Round 2 saw two aborts "without a message" inside
-// ws_search_host (DESIGN.md 3.5); this program asks the questions the code in hand raises, ONE scenario per child
+// ws_search_host (DESIGN.md 5); this program asks the questions the code in hand raises, ONE scenario per child
 // process (forked before anything touches HIP), so that a signal or a runtime abort is attributed to its scenario and
 // whatever the runtime prints on stderr is kept (under pytest's fd capture such a message is lost with the process).
 //
