@@ -867,7 +867,15 @@ __device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch
 // bounded number of tries and flags it instead of hanging the device: in the scratch (ctrl[1]) and in a host-visible
 // word of the context that every synchronising boundary call checks (ws_capi.cpp: check_device_status; ws_device_status
 // for callers of ws_search_device).
-constexpr int kBandRows = 64;
+// Round 4: TWO lanes per pixel.  A third of a step's instructions were the two sliding sums -- the upper neighbour's
+// value slid down a row, the left one's slid along the row: 8 BS LDS reads, their circular-window addresses, 2 x 6 BS dot
+// products -- in ONE lane.  Now a band is 32 rows, lane 2r takes row r's DOWN slide and lane 2r + 1 its RIGHT slide, as one
+// instruction stream over (base, stride, wrap) of "its" lines; the two sums are swapped by one DPP move each and both
+// lanes replay the same decision.  A step has ~100 instructions fewer (of ~700 at 7 x 7), the chain of steps is 5 %
+// longer (more, shorter bands): 3.22 -> 3.12 ms at 7 x 7, 5.05 -> 4.74 ms at 17 x 17 (profiles/r04/left_smooth.txt) --
+// a step's time is mostly NOT its instruction count (see there for what else was tried).
+constexpr int kBandLanes = 64;            // one wave per band
+constexpr int kBandRows = kBandLanes / 2; // rows per band: two lanes per row
 constexpr unsigned long long kEdgeNone = ~0ull;
 constexpr int kBandSpinLimit = 1 << 20;
 
@@ -880,14 +888,16 @@ constexpr int kBandFill = 5;  // steps a window column is requested ahead of its
 // from LDS at the TOP of the decision, for every lane, whether or not it will need them (8 BS registers): one wave per
 // CU has nothing else to hide an LDS round trip behind, and a step used to make fifteen to twenty of them in a row.
 template <int MODE, int BS = 0> // MODE -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
-__global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
+__global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
                                                                          int top_pitch, unsigned long long *edge, int edge_pitch,
                                                                          unsigned int *ctrl, int cwa, int cwb)
 {
     extern __shared__ uint4 ws_smem4[];
-    const int t = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int t = lane >> 1;    // the lane's row of the band (two lanes per row)
+    const int role = lane & 1;  // 0: slides the upper neighbour's value down, stores the results; 1: slides the left one's along
     unsigned int ticket = 0;
-    if (t == 0) ticket = atomicAdd(&ctrl[0], 1u);
+    if (lane == 0) ticket = atomicAdd(&ctrl[0], 1u);
     const int band = (int)__builtin_amdgcn_readfirstlane(ticket);
     const int bsz = BS > 0 ? BS : g.block_size;
     const int half = (bsz - 1) / 2;
@@ -902,7 +912,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     const int nsteps = iw + nrows - 1;
     const unsigned long long *edge_in = edge + (size_t)band * edge_pitch; // written by the band above
     unsigned long long *edge_out = edge + (size_t)(band + 1) * edge_pitch;
-    const bool hands_down = t == nrows - 1 && (band + 1) * kBandRows < ih;
+    const bool hands_down = t == nrows - 1 && role == 0 && (band + 1) * kBandRows < ih;
     float *orow = g.out + (size_t)min(y, height - 1) * g.out_pitch;
     const uint32_t *trow = top + (size_t)min(y, height - 1) * top_pitch * kTopWords;
     // the lane's running state along its row
@@ -921,11 +931,11 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         const int xl = half + min(kBandLag, iw - 1);
         unsigned long long w = kEdgeNone;
         for (int spins = 0;; ++spins) {
-            if (t == 0) w = __hip_atomic_load(&edge_in[xl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!__builtin_amdgcn_ballot_w64(t == 0 && w == kEdgeNone)) break;
+            if (lane == 0) w = __hip_atomic_load(&edge_in[xl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__builtin_amdgcn_ballot_w64(lane == 0 && w == kEdgeNone)) break;
             if (spins > g.spin_limit) {
                 gave_up = true;
-                if (t == 0) {
+                if (lane == 0) {
                     atomicOr(&ctrl[1], 1u);
                     __hip_atomic_store(g.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the host checks it at its next synchronisation
                 }
@@ -946,8 +956,8 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         win.row0 = band * kBandRows - 1; // = (the band's first row) - half - 1
         win.wa = (g.pad_a / cwa) * cwa; win.wb = (g.pad_b / cwb) * cwb;
         for (int c = 0; c < 2 * half + kBandFill; ++c) {
-            lds_fill_column(g.A, g.pitch_a, g.h1, c + g.pad_a, win.A + win.pa(c + g.pad_a) * win.rp, win.row0, lds_rows, t);
-            lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, t);
+            lds_fill_column(g.A, g.pitch_a, g.h1, c + g.pad_a, win.A + win.pa(c + g.pad_a) * win.rp, win.row0, lds_rows, lane);
+            lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, lane);
         }
     }
     // window cost of candidate d at (x, y) from the cost at (x-1, y), from the cost at (x, y-1), or summed whole
@@ -985,7 +995,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
     int store_x = -1;
     auto flush_result = [&]() {
         if (store_x >= 0) {
-            orow[store_x] = vprev;
+            if (role == 0) orow[store_x] = vprev;
             if (hands_down)
                 __hip_atomic_store(&edge_out[store_x], ((unsigned long long)__float_as_uint(vprev) << 32) | cprev, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -1016,13 +1026,13 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         flush_result();
         if constexpr (MODE >= 0) {
             if (k >= 0) {
-                // the windows' lowest columns are k - 64 and k - 64 - max_d (image columns)
-                const int lo_a = max(k - 64, 0) + g.pad_a, lo_b = max(k - 64 - g.max_d, 0) + g.pad_b;
+                // the windows' lowest columns are k - kBandRows - 32 and that - max_d (image columns; 32 columns of slack as ever)
+                const int lo_a = max(k - kBandRows - 32, 0) + g.pad_a, lo_b = max(k - kBandRows - 32 - g.max_d, 0) + g.pad_b;
                 if (lo_a >= win.wa + win.cwa) win.wa += win.cwa;
                 if (lo_b >= win.wb + win.cwb) win.wb += win.cwb;
                 const int cn = k + 2 * half + kBandFill; // first read at step k + kBandFill
-                lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, t);
-                lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, t);
+                lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, lane);
+                lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, lane);
             }
         }
         // this step's inputs leave their slot, the inputs of step k + kBandDepth take it
@@ -1045,8 +1055,11 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
         if (k < 0) return; // (uniform)
         // the upper neighbour (y-1, x): the lane above finished it in the previous step
         // (wave_shr:1 -- one DPP move each; __shfl_up goes through the LDS crossbar and its latency)
-        float upf = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(vprev), 0x138, 0xf, 0xf, false));
-        uint32_t c_above = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cprev, 0x138, 0xf, 0xf, false);
+        // (the row above is two lanes up: both of its lanes hold the same result)
+        const int v1 = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(vprev), 0x138, 0xf, 0xf, false);
+        const int c1 = __builtin_amdgcn_update_dpp(0, (int)cprev, 0x138, 0xf, 0xf, false);
+        float upf = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, v1, 0x138, 0xf, 0xf, false));
+        uint32_t c_above = (uint32_t)__builtin_amdgcn_update_dpp(0, c1, 0x138, 0xf, 0xf, false);
         if (t == 0) { upf = 0.0f; c_above = kTopNone; } // band 0: the ring row above the interior holds 0
         if (band > 0) { // (uniform) lane 0's upper neighbour belongs to the band above
             for (int spins = 0; !gave_up; ++spins) { // (only if the band above fell behind: it was ahead at start-up)
@@ -1054,7 +1067,7 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 if (!__builtin_amdgcn_ballot_w64(wait)) break;
                 if (spins > g.spin_limit) {
                     gave_up = true;
-                    if (t == 0) {
+                    if (lane == 0) {
                         atomicOr(&ctrl[1], 1u);
                         __hip_atomic_store(g.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
@@ -1068,39 +1081,55 @@ __global__ void __launch_bounds__(kBandRows) ws_smooth_left_bands_kernel(const S
                 c_above = (uint32_t)w;
             }
         }
-        // (BS > 0) the lines the two common sliding sums would need, requested now
+        // (BS > 0) the lines of the two common sliding sums, read and summed NOW by both lanes of the pixel, whether or not
+        // the decision below will ask for them: lane 0 of the pixel slides the upper neighbour's value down (window rows
+        // y + half in / y - 1 - half out: one element per window COLUMN, a stride of rp dwords that wraps around the
+        // circular window), lane 1 slides the left neighbour's value along the row (window columns x + half in /
+        // x - 1 - half out: consecutive dwords of one column).  One instruction stream: element i of a line sits at
+        // base + i * stride, minus the window's span once it runs past the window's end.
         constexpr int NB = BS > 0 ? BS : 1;
-        uint32_t da_in[NB], db_in[NB], da_out[NB], db_out[NB]; // `up` slid down: window rows y + half (in) / y - 1 - half (out)
-        uint32_t sa_in[NB], sb_in[NB], sa_out[NB], sb_out[NB]; // `l` slid right: window columns x + half (in) / x - 1 - half (out)
+        uint32_t pre_down = 0, pre_right = 0; // c_above slid down to (x, y) / lcost slid right to (x, y): valid if those were
         if (MODE >= 0 && BS > 0 && other_can_win) { // (uniform)
             const int xq = half + min(max(xs, 1), iw - 1);                  // (lanes outside their row read somewhere harmless)
             const int du = min(max((int)upf, 1), g.max_d), dl = min(max((int)lv, 1), g.max_d);
             const int r_in = y + half - win.row0, r_out = y - 1 - half - win.row0, r_col = y - half - win.row0;
-            const uint32_t *pca_in = win.A + win.oa(xq + half + g.pad_a) + r_col, *pca_out = win.A + win.oa(xq - 1 - half + g.pad_a) + r_col;
-            const uint32_t *pcb_in = win.B + win.ob(xq + half - dl + g.pad_b) + r_col, *pcb_out = win.B + win.ob(xq - 1 - half - dl + g.pad_b) + r_col;
+            const int span_a = win.cwa * win.rp, span_b = win.cwb * win.rp;
+            // first elements (dword offsets inside the windows) and strides
+            int a_in, b_in, a_out, b_out, stride;
+            if (role == 0) {
+                a_in = win.oa(xq - half + g.pad_a) + r_in;  b_in = win.ob(xq - half - du + g.pad_b) + r_in;
+                a_out = a_in + (r_out - r_in);              b_out = b_in + (r_out - r_in);
+                stride = win.rp;
+            } else {
+                a_in = win.oa(xq + half + g.pad_a) + r_col;      b_in = win.ob(xq + half - dl + g.pad_b) + r_col;
+                a_out = win.oa(xq - 1 - half + g.pad_a) + r_col; b_out = win.ob(xq - 1 - half - dl + g.pad_b) + r_col;
+                stride = 1;
+            }
+            // (a column's dwords never wrap; a row's elements do when their column index passes the window's end: then the
+            // offset is at least `span` -- columns are rp dwords apart and the rows add less than rp)
+            uint32_t va_in[NB], vb_in[NB], va_out[NB], vb_out[NB];
 #pragma unroll
             for (int i = 0; i < BS; ++i) {
-                const int ia = win.oa(xq - half + i + g.pad_a), ib = win.ob(xq - half + i - du + g.pad_b);
-                da_in[i] = win.A[ia + r_in]; db_in[i] = win.B[ib + r_in];
-                da_out[i] = win.A[ia + r_out]; db_out[i] = win.B[ib + r_out];
-                sa_in[i] = pca_in[i]; sb_in[i] = pcb_in[i];
-                sa_out[i] = pca_out[i]; sb_out[i] = pcb_out[i];
+                va_in[i] = win.A[a_in]; vb_in[i] = win.B[b_in];
+                va_out[i] = win.A[a_out]; vb_out[i] = win.B[b_out];
+                a_in += stride; b_in += stride; a_out += stride; b_out += stride;
+                if (a_in >= span_a) a_in -= span_a;
+                if (a_out >= span_a) a_out -= span_a;
+                if (b_in >= span_b) b_in -= span_b;
+                if (b_out >= span_b) b_out -= span_b;
             }
-        }
-        auto pre_slide_down = [&](uint32_t c_up) -> uint32_t {
             __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): ONE wait for all the lines instead of one per dword
-            uint32_t acc = c_up;
+            uint32_t acc = role == 0 ? c_above : lcost;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_in[i], db_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(da_out[i], db_out[i]);
-            return acc;
-        };
-        auto pre_slide = [&](uint32_t c_prev) -> uint32_t {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            uint32_t acc = c_prev;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_in[i], sb_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(sa_out[i], sb_out[i]);
-            return acc;
-        };
+            for (int i = 0; i < NB; ++i)
+                acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(va_in[i], vb_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(va_out[i], vb_out[i]);
+            // the pixel's other lane has the other sum: quad_perm [1, 0, 3, 2]
+            const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xb1, 0xf, 0xf, false);
+            pre_down = role == 0 ? acc : other;
+            pre_right = role == 0 ? other : acc;
+        }
+        auto pre_slide_down = [&](uint32_t) -> uint32_t { return pre_down; };
+        auto pre_slide = [&](uint32_t) -> uint32_t { return pre_right; };
         constexpr bool PRE = MODE >= 0 && BS > 0;
         if (in) {
             float v;
@@ -1257,14 +1286,14 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     unsigned long long *edge = reinterpret_cast<unsigned long long *>(sync + 64);
     unsigned int *ctrl = reinterpret_cast<unsigned int *>(sync);
     // the planes' moving windows in LDS when the marching kernel left its planes behind and they fit
-    const int cwa = 2 * half + 66 + kBandFill, cwb = g.max_d + 2 * half + 66 + kBandFill, rp = kBandRows + 2 * half + 2;
+    const int cwa = 2 * half + kBandRows + 34 + kBandFill, cwb = g.max_d + 2 * half + kBandRows + 34 + kBandFill, rp = kBandRows + 2 * half + 2;
     const size_t lds = (size_t)(cwa + cwb) * rp * sizeof(uint32_t);
     auto launch = [&](auto kernel, size_t bytes) -> hipError_t {
         if (bytes > 48 * 1024) {
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (err != hipSuccess) return err;
         }
-        hipLaunchKernelGGL(kernel, dim3(nbands), dim3(kBandRows), bytes, st, a, top3, g.w1, edge, (int)pitch, ctrl, cwa, cwb);
+        hipLaunchKernelGGL(kernel, dim3(nbands), dim3(kBandLanes), bytes, st, a, top3, g.w1, edge, (int)pitch, ctrl, cwa, cwb);
         return hipGetLastError();
     };
     if (canon && lds <= 152 * 1024 && 2 * half + 1 + kBandRows <= 128) {
