@@ -141,6 +141,17 @@ def test_cxx_facade_compiles_and_links(wslib, tmp_path):
     assert os.path.exists(exe)
 
 
+def test_opencv_adapters_compile_against_a_stub(tmp_path):
+    """The WSAMD_WITH_OPENCV block of the facade (wsamd::view(cv::Mat), wsamd::to_cv) -- the code a maintainer of the
+    reference compiles -- has no OpenCV to be compiled against in this image.  It is compiled
+    and run here against tests/cxx/opencv_stub/opencv2/core.hpp, a dozen declarations with cv::Mat's names and
+    signatures: a syntax-and-types check, NOT a check against OpenCV."""
+    exe = str(tmp_path / "opencv_adapter_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "cxx", "opencv_stub"), "-I", ROOT,
+                           "-o", exe, os.path.join(ROOT, "tests", "cxx", "opencv_adapter_check.cpp")])
+    assert b"opencv adapters ok" in subprocess.check_output([exe])
+
+
 def test_mesh_writer_matches_the_restatement(wslib, oracle, tmp_path):
     """WriteMesh (reconstruction.cpp:72-149) is host-only: text identical to the Python restatement."""
     rng = np.random.default_rng(4)
