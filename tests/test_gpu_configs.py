@@ -4,6 +4,8 @@ meeting in the key plane before the parabola), and a MotorcycleE-shaped unequal 
 (results/Rectified/trainingH/MotorcycleE: 1481 x 1038 left, 1495 x 1052 right, SURVEY.md section 2
 row 15).  Full maps are checked through size-independent properties, oracle row bands bit for bit.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -217,3 +219,38 @@ def test_the_planners_plan_is_within_5_percent_of_the_best_forced_one(wslib, cfg
     print("%s: auto %.4f ms (%s, %d threads); best forced %.4f ms %s %s" % (name, auto_ms, auto_plan["kernel"], auto_plan["threads"],
                                                                             best_ms, best_key, results[best_key][1]))
     assert auto_ms <= 1.05 * best_ms, (name, auto_ms, auto_plan, {k: round(v[0], 4) for k, v in results.items()})
+
+
+@pytest.mark.parametrize("view", ["left", "right"])
+def test_device_images_at_any_byte_alignment_and_stride(wslib, oracle, view):
+    """The marching kernel reads the caller's CV_8UC3 bytes itself (round 4): 16-byte blocks by LDS-DMA from wherever
+    a row starts, unpacked with the row's own byte phase.  Device-resident images cut out of a byte buffer at every
+    phase of 16, with row strides that are odd, a multiple of 4 but not 16, and a multiple of 16 -- cv::Mat ROIs and
+    tightly packed rows of any width -- SSD and SAD, the plain and the halo-exchange kernels, both views; the buffers
+    around the images are poisoned (a kernel that reads a neighbour's bytes as its own shows)."""
+    import torch
+    rng = np.random.default_rng(17)
+    w, h, bs = 333, 40, 7
+    left, right, _ = make_pair(w, h, 48, seed=71)
+    left[20, 100] = 0
+    right[21, 90] = 0
+    for cost, maxd in (("ssd", 48), ("sad", 300)):
+        want = (oracle.block_left if view == "left" else oracle.block_right)(left, right, bs, 0, maxd, cost=cost, threads=8)
+        p = wslib.make_params(wslib.VIEW_LEFT if view == "left" else wslib.VIEW_RIGHT, bs, 0, maxd, 1.0, cost)
+        with wslib.WindowSearch(0) as ctx:
+            for off, stride in ((0, 3 * w), (1, 3 * w), (2, 3 * w + 1), (3, 3 * w + 5), (5, 1004), (7, 1008), (11, 1024), (13, 3 * w + 2), (15, 1040)):
+                bufs = []
+                for img in (left, right):
+                    raw = torch.from_numpy(rng.integers(0, 256, size=off + stride * h + 64, dtype=np.uint8)).cuda()
+                    view2d = raw[off:off + stride * h].view(h, stride)
+                    view2d[:, :3 * w] = torch.from_numpy(img.reshape(h, 3 * w)).cuda()
+                    bufs.append((raw, raw.data_ptr() + off, stride))
+                out = torch.full((h, w), -3.0, dtype=torch.float32, device="cuda")
+                Li = wslib._Image(bufs[0][1], w, h, bufs[0][2])
+                Ri = wslib._Image(bufs[1][1], w, h, bufs[1][2])
+                lib = wslib.load_library()
+                rc = lib.ws_search_device(ctx._h, ctypes.byref(p), ctypes.byref(Li), ctypes.byref(Ri), out.data_ptr(), w, None)
+                assert rc == 0, lib.ws_last_error(ctx._h)
+                torch.cuda.synchronize()
+                assert "march" in ctx.last_launch()["kernel"]
+                assert np.array_equal(out.cpu().numpy().astype(np.float64), want), (view, cost, off, stride)
