@@ -46,12 +46,21 @@ PROFILE_ROUND = "r04"  # profiles/<round>/traffic_<workload>.json: PMC figures o
 KERNEL_SOURCES = ["ws_march_kernel.h", "ws_march.hip", "ws_march_nd4.hip", "ws_device.h", "ws_kernels.h"]
 
 
-def kernel_sources_sha1():
+def kernel_sources_sha1(read=None):
+    """SHA-1 of the marching kernel's sources with comments and whitespace stripped: a reworded comment does not
+    orphan the PMC summaries under profiles/, a changed instruction does."""
     import hashlib
+    import re
     h = hashlib.sha1()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "stereo_reconstruction_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        if read is None:
+            with open(os.path.join(ROOT, "stereo_reconstruction_amd", "csrc", name), "rb") as f:
+                text = f.read().decode("utf-8", "replace")
+        else:
+            text = read(name)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()
 
 # A step is one pass of the hot path over one BATCH of pairs of the workload's shape (distinct images, all resident

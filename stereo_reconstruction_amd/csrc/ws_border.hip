@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) ws_refine_planes_kernel(const RefineArgs 
     if (d - 1 < g.d_lo || d + 1 > g.d_hi || xb - 1 < g.b_lo || xb + 1 > g.b_hi) return;
     // costs at d-1 (target column +1), d, d+1 (target column -1); the three target windows overlap,
     // so a row costs ww + 2 target loads; for SSD the three sums of b^2 come from the same pixels (the marching
-    // kernel's bias plane carries a per-strip correction term besides them, ws_prepass.hip, and is not read here)
+    // kernel's bias rows live in its LDS only and carry a per-strip correction term besides them: not read here)
     long long cm = 0, c0 = 0, cp = 0;
     for (int r = 0; r < g.wh; ++r) {
         const uint32_t *pa = g.A + (size_t)(y + g.wy0 + r) * g.pitch_a + (x + g.wx0 + g.pad_a);

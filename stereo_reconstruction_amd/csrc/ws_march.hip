@@ -1,5 +1,5 @@
 // ws_march.hip -- the hot kernel of the WindowSearch path on gfx950 (CDNA4), plus the overview of
-// all device code:  ws_prepass.hip (pack + bias + border in one launch), ws_march.hip (marching kernel, tiling plan),
+// all device code:  ws_march_kernel.h / ws_march.hip (marching kernel, tiling plan), ws_prepass.hip (dword planes for the side kernels),
 // ws_border.hip (brute force, border ring, refine, varBlock), ws_smooth.hip (smoothFactor passes),
 // ws_consumers.hip (warp, Reconstruction-side maps), ws_device.h (shared helpers).
 //
@@ -8,24 +8,23 @@
 // candidate with the strictly smallest value.  It re-sums the window for every (pixel, d).
 //
 // What runs here instead (same integers, same winner):
-//   ws_prepare_kernel  one launch of independent workgroups before the hot kernel:
-//                    pack: BGR bytes -> one dword per pixel (B | G<<8 | R<<16), zero padded plane,
-//                          mirrored in x for the right view;
-//                    bias: per (row, B column) the validity poison, and for SSD the box sum of the
-//                          squared target pixels (the part of sum (a-b)^2 that does not need a);
-//                    left view: the pixels outside the marching interior (border zeros).
 //   ws_march_kernel  the hot kernel.  A workgroup owns a tile of X*nxr columns and a strip of
 //                    rows; thread (r, c) owns X consecutive columns and ND consecutive
 //                    disparities and keeps their X*ND window sums in registers while the
 //                    workgroup marches down the strip one row at a time:
-//                      - rows are staged once per step into an LDS ring and re-used by every
-//                        disparity chunk of the tile,
+//                      - the caller's CV_8UC3 rows travel HBM -> LDS as the bytes they are (LDS-DMA) and are
+//                        unpacked there, two stages ahead of their use: one dword per pixel (B | G<<8 | R<<16) in
+//                        an LDS ring every disparity chunk of the tile reads, zero outside the image, mirrored in x
+//                        for the right view; SSD: the box sum of the squared target pixels (the part of
+//                        sum (a-b)^2 that does not need a) is summed by the same lanes (ws_march_kernel.h),
 //                      - per row and d a prefix chain of v_sad_u8 / v_dot4_u32_u8 (one
 //                        instruction per pixel pair, 3 channels at once) gives all horizontal
 //                        window sums by differences; the row leaving the window is removed the
 //                        same way (sliding box filter, exact in integers),
 //                      - the running minimum is a single signed v_min on (cost << k | tie tag),
 //                      - the d-chunks of a pixel meet through one ds_min_u64 per thread and row.
+//                    A left-view search with smoothFactor 1 is this ONE launch (it writes the border zeros too).
+//   ws_pack_kernel   BGR bytes -> zero padded dword planes, only for the kernels below that read planes.
 //   ws_ring_kernel   right-view border ring (clipped windows): a small marching kernel, lanes over d.
 //   ws_linear_kernel LinearSearch through LDS.
 //   ws_generic_kernel  literal per-pixel brute force: window sizes without a marching instantiation

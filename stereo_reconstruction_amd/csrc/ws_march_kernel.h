@@ -229,7 +229,7 @@ __device__ __forceinline__ uint32_t from_lane_plus(uint32_t v)
 #ifndef WS_FUSE
 #define WS_FUSE 1
 #endif
-constexpr bool kFuseSsd = WS_FUSE != 0; // build-time knob for A/B runs (tools/variants.py); the pre-pass follows it (march_fused)
+constexpr bool kFuseSsd = WS_FUSE != 0; // build-time knob for A/B runs (tools/variants.py); the column sums follow it (kMul)
 
 template <int X, int ND, int WW, bool SSD, bool KEY>
 __device__ __forceinline__ void march_load(uint32_t (&pa)[X + WW - 1], uint32_t (&pb)[X + WW + ND - 2], uint32_t (&bi)[X + ND - 1],
@@ -293,8 +293,8 @@ __device__ __forceinline__ void march_row(int32_t (&V)[X][ND], int32_t (&best)[X
 // centred bytes (~a = -a - 1) (-a - 1) . b = -b - a . b (the 4th byte of b is 0 either way).  The chain's differences are
 // then  (cross sum of the entering row) - (cross sum of the leaving row) + K * (sum of the leaving row's target bytes
 // over the window), K = 255 or -1: the last term does not depend on the reference image, only on (row, target
-// column), and the pre-pass folds its running total over the rows that left the strip so far into the bias plane
-// (ws_prepass.hip, bias_strip: bias = (sum b^2 + 2 K E) << LT).  V and the bias wrap around in 32 bits by themselves,
+// column), and the stage that sums the bias rows (ws_march_kernel, produce) folds its running total over the rows that
+// left the strip so far into them: bias = (sum b^2 + 2 K E) << LT.  V and the bias wrap around in 32 bits by themselves,
 // their sum -- the key -- is exact.  One difference, one accumulate and one chain per step instead of two each:
 // 7.0 instead of 9.0 instructions per hypothesis in the steady state (+ X + WW - 1 v_not per thread and step).
 template <int X, int ND, int WW, bool CENTRED>
