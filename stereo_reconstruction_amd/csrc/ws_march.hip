@@ -302,7 +302,11 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         // workgroups share a CU, four waves per SIMD, and a round is twice as many workgroups -- the runtime's
         // occupancy figure where a device is there to ask, that rule of thumb for ws_plan without one.)
         const int pnd = p.nd_per_thread;
-        const int slots = march_slots_per_cu(c, pnd, p.threads, p.halo != 0);
+        p.lds_bytes = (size_t)march_lds_layout(X, pnd, c.ww, c.wh, c.ssd != 0, p.halo && !c.ssd && march_pk_window(c.ww, c.wh), runs, p.nch).bytes;
+        if (p.lds_bytes == 0 || p.lds_bytes > 160 * 1024) return 0.0; // (0: a tile row wider than the kernel's stage area)
+        // (the registers' answer, capped by what the CU's 160 KB of LDS hold: the kernel's LDS is dynamic, the runtime is
+        // asked without it -- and since round 4 a workgroup's LDS carries the stage area and the descriptors as well)
+        const int slots = std::max(1, std::min(march_slots_per_cu(c, pnd, p.threads, p.halo != 0), (int)(160 * 1024 / p.lds_bytes)));
         auto strip_cost = [&](int st, int rows) { return ceil_div(p.tiles * st, num_cus * slots) * (rows + 0.5 * (c.wh - 1) + 3.0); };
         int strips = 1;
         if (tune_strip_rows > 0) {
@@ -319,8 +323,6 @@ static bool march_plan_threads(const Canon &c, int num_cus, int tune_nxr, int tu
         }
         p.strip_rows = ceil_div(out_h, strips);
         p.strips = ceil_div(out_h, p.strip_rows);
-        p.lds_bytes = (size_t)march_lds_layout(X, pnd, c.ww, c.wh, c.ssd != 0, p.halo && !c.ssd && march_pk_window(c.ww, c.wh), runs, p.nch).bytes;
-        if (p.lds_bytes == 0 || p.lds_bytes > 160 * 1024) return 0.0; // (0: a tile row wider than the kernel's stage area)
         // a row step of the halo-exchange kernel against the plain one's, from the instruction counts (march_pk_halo);
         // every d-group pass beyond the first ~2 % for the key plane's round trip (gpurun_out/r3_chunks.txt)
         // (6.19 against 7.52 instructions per hypothesis at 9 x 9, profiles/r03/isa_op_histogram.txt; a thread of the halo
