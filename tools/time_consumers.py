@@ -20,6 +20,13 @@ for (w, h, d) in ((900, 750, 200), (1500, 1000, 256), (3840, 2160, 255)):
     disp8 = np.clip(gt, 0, 255).astype(np.float32)
     disp8[h // 3:h // 3 + 20, w // 4:w // 4 + 60] = 0
     K = np.array([[3000, 0, w / 2], [0, 3000, h / 2], [0, 0, 1]], dtype=np.float32)
+    # (two untimed calls of each first: the library's pinned stages and device buffers for this size are allocated by the
+    # first call -- round 3's table timed that allocation into its first size: 2.27 ms at 900 x 750 against 0.53 ms at
+    # 1500 x 1000)
+    for _ in range(2):
+        filt = ctx.remove_disparity_outliers(disp8, 500, 1.5, 0.8)
+        depth = ctx.convert_disparity_to_depth(filt, 3000.0, 1.0)
+        ctx.back_project(depth, K, right)
     t0 = time.perf_counter()
     for _ in range(reps):
         filt = ctx.remove_disparity_outliers(disp8, 500, 1.5, 0.8)
