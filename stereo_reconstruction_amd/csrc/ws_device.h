@@ -29,7 +29,7 @@ __host__ __device__ constexpr int march_region_dwords(int n, int nreg)
 
 // ---- the marching kernel's LDS (one definition for the kernel and for the planner that prices it) ----------------
 // [stage area, compile-time offsets: 2 raw rows of the reference image | 2 raw rows of the target image | SSD: 2 rows of
-//  column sums]  then  ring A | ring B | 2 bias rows (SSD) | 2 rows of merge slots.
+//  column sums]  then  the stages' descriptors | ring A | ring A complemented (SSD) | ring B | 2 bias rows (SSD) | 2 rows of merge slots.
 // The stage area is sized for the widest tile row any plan makes, so that its addresses are immediates in the code of the
 // stages (ws_march_kernel.h, produce) instead of scalar registers held across the chains.
 // bytes a raw row buffer needs (raw_dma): up to 15 of alignment in front, 3 per pixel, a dword of over-read behind
@@ -80,7 +80,8 @@ __host__ __device__ inline MarchLds march_lds_layout(int x, int nd, int ww, int 
     l.roles_a = (l.n_a4 / 4 + 63) / 64;
     l.nslots = (l.roles_b + l.roles_a + nwaves - 1) / nwaves;
     l.desc_bytes = 16 * threads * l.nslots;
-    l.bytes = march_stage_bytes(nd, ssd) + l.desc_bytes + 4 * (l.nr * (l.a_w + l.b_w) + 2 * l.bi_w) + 2 * tx * (ssd ? 8 : 4);
+    // (SSD: ring A twice -- the reference rows as they are and complemented, what the fused chain multiplies a leaving row by)
+    l.bytes = march_stage_bytes(nd, ssd) + l.desc_bytes + 4 * (l.nr * ((ssd ? 2 : 1) * l.a_w + l.b_w) + 2 * l.bi_w) + 2 * tx * (ssd ? 8 : 4);
     if (l.n_a4 > kStageMaxNA || l.n_b4 > march_max_nb(nd)) l.bytes = 0;
     return l;
 }

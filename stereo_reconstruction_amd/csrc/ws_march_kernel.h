@@ -324,7 +324,10 @@ __device__ __forceinline__ void march_fused_ssd(int32_t (&V)[X][ND], int32_t (&b
             V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
             const int32_t k0 = (int32_t)bi[x - j + ND - 1] + V[x][j];
             const int32_t k1 = (int32_t)bi[x - j + ND - 2] + V[x][j + 1];
-            best[x] = min(best[x], min(k0, k1));
+            // (spelled out: the compiler splits min(best, min(k0, k1)) into two v_min_i32 for a third of the columns; the
+            // first pair of a step has nothing to compare with yet -- best[] enters as INT_MAX)
+            if (j == 0) best[x] = min(k0, k1);
+            else asm("v_min3_i32 %0, %1, %2, %3" : "=v"(best[x]) : "v"(best[x]), "v"(k0), "v"(k1));
         }
     }
 }
@@ -377,7 +380,10 @@ __device__ __forceinline__ void march_fused_ssd_halo(int32_t (&V)[X][ND], int32_
             V[x][j + 1] = (int32_t)((w1 << shift) + (uint32_t)V[x][j + 1]);
             const int32_t k0 = (int32_t)bi[x - j + ND - 1] + V[x][j];
             const int32_t k1 = (int32_t)bi[x - j + ND - 2] + V[x][j + 1];
-            best[x] = min(best[x], min(k0, k1));
+            // (spelled out: the compiler splits min(best, min(k0, k1)) into two v_min_i32 for a third of the columns; the
+            // first pair of a step has nothing to compare with yet -- best[] enters as INT_MAX)
+            if (j == 0) best[x] = min(k0, k1);
+            else asm("v_min3_i32 %0, %1, %2, %3" : "=v"(best[x]) : "v"(best[x]), "v"(k0), "v"(k1));
         }
     }
 }
@@ -612,7 +618,14 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
     static_assert(kStage == oG + 2 * kGB && kStage % 16 == 0, "stage area");
     static_assert(MAXT <= kStageThreads, "the stage area is sized for workgroups of up to kStageThreads");
     uint32_t *ringA = smem + (kStage + L.desc_bytes) / 4; // (behind the stage area: the stages' per-thread descriptors)
-    uint32_t *ringB = ringA + NR * a_w;
+    // SSD: a twin of ring A with every dword complemented -- what the fused chain multiplies a LEAVING row's target pixels
+    // by ((255 - a) . b, march_fused_ssd).  The unpacking lane writes both; round 3 complemented in the chains' threads: 14
+    // v_not per thread and step (X + WW - 1 of ~500 instructions, in every wave) against one more ds_write_b128 and 4
+    // v_not per quad of image A in ONE wave.
+    constexpr bool TWIN = SSD && kFuseSsd;
+    constexpr int NRA = TWIN ? 2 * NR : NR; // rows of ring A's space
+    uint32_t *ringAc = ringA + NR * a_w;
+    uint32_t *ringB = ringA + NRA * a_w;
     int32_t *biasr = reinterpret_cast<int32_t *>(ringB + NR * b_w);
     slot_t *slots = reinterpret_cast<slot_t *>(biasr + 2 * bi_w);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32 *)smem; // LDS byte address of the stage area
@@ -848,7 +861,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                         t = px[1]; px[1] = px[2]; px[2] = t;
                     }
                     const uint32_t phys = d.y & 0xffffu;
-                    const uint32_t ringB_u = lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * a_w + slot_u * b_w);
+                    const uint32_t ringB_u = lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NRA * a_w + slot_u * b_w);
                     if (d.w & kDescRing) lds_store128(ringB_u + phys, make_uint4(px[0], px[1], px[2], px[3]));
                     if constexpr (SSD) {
                         // column sums: row iu enters, row iu - WH leaves and joins the correction term.  Plain bytes: with
@@ -862,7 +875,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                         if (iu >= WH) {
                             int slot_l = slot_u + 2; // row iu - WH
                             if (slot_l >= NR) slot_l -= NR;
-                            const uint4 lv = lds_load128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * a_w + slot_l * b_w) + phys);
+                            const uint4 lv = lds_load128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NRA * a_w + slot_l * b_w) + phys);
                             const uint32_t lp[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -902,7 +915,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                             }
                             static_assert(kPoison == 1 << 29, "the descriptor's poison bits are shifted into place");
                             if (d.w & kDescBias)
-                                lds_store128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NR * (a_w + b_w) + ((iu + WH + 1) & 1) * bi_w) + (d.y >> 16),
+                                lds_store128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(NRA * a_w + NR * b_w + ((iu + WH + 1) & 1) * bi_w) + (d.y >> 16),
                                              make_uint4(o[0], o[1], o[2], o[3]));
                         }
                     }
@@ -919,8 +932,11 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                         uint32_t t = px[0]; px[0] = px[3]; px[3] = t;
                         t = px[1]; px[1] = px[2]; px[2] = t;
                     }
-                    if (d.w & kDescRing)
-                        lds_store128(lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(slot_u * a_w) + d.y, make_uint4(px[0], px[1], px[2], px[3]));
+                    if (d.w & kDescRing) {
+                        const uint32_t at = lds0 + (uint32_t)(kStage + L.desc_bytes) + 4u * (uint32_t)(slot_u * a_w) + d.y;
+                        lds_store128(at, make_uint4(px[0], px[1], px[2], px[3]));
+                        if constexpr (TWIN) lds_store128(at + 4u * (uint32_t)(NR * a_w), make_uint4(~px[0], ~px[1], ~px[2], ~px[3]));
+                    }
                 }
             }
         }
@@ -1008,6 +1024,7 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
         if (worker) {
             const uint32_t *addA = ringA + add_slot * a_w + ia, *addB = ringB + add_slot * b_w + ib;
             const uint32_t *subA = ringA + sub_slot * a_w + ia, *subB = ringB + sub_slot * b_w + ib;
+            const uint32_t *subAc = ringAc + sub_slot * a_w + ia; // (TWIN: the leaving row's reference pixels, complemented)
             slot_t *sl = slots + (oi & 1) * tx + r;
             if constexpr (PK) {
                 uint32_t bestp[X];
@@ -1042,18 +1059,14 @@ __global__ void __launch_bounds__(MAXT) ws_march_kernel(const MarchArgs g)
                     lds_run<X, NREG>(pa, addA, ro_a);
                     lds_run<X + ND - 1, NREGB>(pb, addB, ro_b);
                     lds_run<X + ND - 1, NREGB>(bi, reinterpret_cast<const uint32_t *>(brow), ro_bi);
-                    lds_run<X, NREG>(qa, subA, ro_a);
+                    lds_run<X, NREG>(qa, subAc, ro_a);
                     lds_run<X + ND - 1, NREGB>(qb, subB, ro_b);
-#pragma unroll
-                    for (int i = 0; i < X; ++i) qa[i] = ~qa[i];
                     march_fused_ssd_halo<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
                 } else if constexpr (SSD && kFuseSsd) { // row a enters and row a - WH leaves in one chain
                     uint32_t pa[X + WW - 1], pb[X + WW + ND - 2], qa[X + WW - 1], qb[X + WW + ND - 2], bi[X + ND - 1];
                     march_load<X, ND, WW, true, true>(pa, pb, bi, addA, ro_a, addB, ro_b, brow, ro_bi);
-                    lds_run<X + WW - 1, NREG>(qa, subA, ro_a);
+                    lds_run<X + WW - 1, NREG>(qa, subAc, ro_a);
                     lds_run<X + WW + ND - 2, NREGB>(qb, subB, ro_b);
-#pragma unroll
-                    for (int i = 0; i < X + WW - 1; ++i) qa[i] = ~qa[i];
                     march_fused_ssd<X, ND, WW, CENTRED>(V, best, pa, pb, qa, qb, bi, shift);
                 } else {
                     march_row<X, ND, WW, SSD, CENTRED, -1, false>(V, best, subA, ro_a, subB, ro_b, nullptr, 0, shift);
