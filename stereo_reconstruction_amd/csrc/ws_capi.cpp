@@ -324,15 +324,15 @@ private:
     static CopyPool *instance_;
     CopyPool()
     {
-        unsigned n = std::thread::hardware_concurrency();
-        n = n >= 16 ? 7 : n >= 8 ? 3 : n >= 4 ? 1 : 0; // helpers beside the calling thread
+        unsigned cores = std::thread::hardware_concurrency();
         // one process per GPU on a node (torchrun / mpirun export the local world size): the ranks share the host's cores
         for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"})
             if (const char *e = getenv(name)) {
                 const int ranks = atoi(e);
-                if (ranks > 1) n = (unsigned)std::max(0, (int)(n + 1) / ranks - 1);
+                if (ranks > 1) cores /= (unsigned)ranks;
                 break;
             }
+        unsigned n = cores >= 16 ? 7 : cores >= 8 ? 3 : cores >= 4 ? 1 : 0; // helpers beside the calling thread
         if (const char *e = getenv("WS_COPY_THREADS")) n = (unsigned)std::max(0, std::min(31, atoi(e) - 1));
         for (unsigned i = 0; i < n; ++i) {
             try { workers_.emplace_back([this] { loop(); }); }
