@@ -51,7 +51,7 @@ struct Job { // one pair in flight on the batched host path
     int w = 0, h = 0, out_stride = 0, dtype = 0;
     bool pending = false; // searched (or being searched), result not yet on its way to user_out
     HostBuf h_left, h_right; // gathered rows of images that do not cross as one span (gather_rows), or their stage
-    HostBuf h_out;           // stage of a map whose buffer cannot be registered (HostSpan)
+    HostBuf h_out;           // stage of a pageable map (HostSpan)
     int out_span = -1;       // index of this pair's output span in ws_context::batch_spans
 };
 
@@ -1142,7 +1142,7 @@ static int search_host_banded(ws_context *ctx, const ws_params *p, const ws_imag
     const int esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     uint8_t *dl = static_cast<uint8_t *>(ctx->d_left.p), *dr = static_cast<uint8_t *>(ctx->d_right.p);
     float *scratch = static_cast<float *>(ctx->d_out.p);
-    // the caller's three buffers for the duration of the call (HostSpan: registered, caller-pinned or staged)
+    // the caller's three buffers for the duration of the call (HostSpan: caller-pinned or staged)
     HostSpan sp[3];
     sp[0].p = const_cast<uint8_t *>(left->data); sp[0].n = span_l; sp[0].stage = &ctx->h_left;
     sp[1].p = const_cast<uint8_t *>(right->data); sp[1].n = span_r; sp[1].stage = &ctx->h_right;
@@ -1284,7 +1284,7 @@ int ws_search_host(ws_context *ctx, const ws_params *p, const ws_image *left, co
     const int esz = out_dtype == WS_OUT_F32 ? 4 : 8;
     const int wire = wire_for(p, left, right);
     if (wire == kWireI16 && (rc = ensure(ctx, ctx->d_out16, (size_t)ow * oh * 2)) != WS_OK) return rc;
-    // The caller's buffers for the duration of the call (HostSpan): registered, caller-pinned or staged -- every
+    // The caller's buffers for the duration of the call (HostSpan): caller-pinned or staged -- every
     // host copy of this library goes the same way, whatever the band setting of the moment, and none through the
     // runtime's pageable path.
     const size_t span_o = ((size_t)out_stride * (oh - 1) + ow) * esz;
