@@ -38,15 +38,44 @@ struct RingArgs {
 };
 
 constexpr int kRingTile = 8;                          // a workgroup owns up to 8 x 8 ring pixels
+constexpr int kRingBatch = 8;                         // rows of plane B in flight per thread while a tile's strip is staged
 constexpr int kRingMaxHalf = 8;                       // right-view marching windows: (2 half)^2 <= 16 x 16
 constexpr int kRingCols = kRingTile + 2 * kRingMaxHalf; // window columns under a tile (<= tile + 2 half - 1)
+constexpr int kRingSlack = 32;                         // words behind the staged strips that a row's unused columns may read
 
-// cost of one pixel pair (SSD: without a^2, which is the same for every d)
+// One pixel pair's term with nothing to add it to (SSD: a dot product; the whole cost of a pair is b.b - 2 a.b, a^2
+// being the same for every d).  Spelled out: for a zero accumulator the compiler takes the in-place v_dot4c form and
+// clears its destination with a v_mov first.
 template <int MODE> // 0 SAD, 1 SSD, 2 SSD on centred planes
-__device__ __forceinline__ int32_t ring_px(uint32_t a, uint32_t b)
+__device__ __forceinline__ uint32_t ring_dot0(uint32_t a, uint32_t b)
 {
-    if constexpr (MODE == 0) return (int32_t)pix_sad(a, b, 0u);
-    else return (int32_t)pix_dot<MODE == 2>(b, b, 0u) - 2 * (int32_t)pix_dot<MODE == 2>(a, b, 0u);
+    uint32_t r;
+    if constexpr (MODE == 0) asm("v_sad_u8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    else if constexpr (MODE == 1) asm("v_dot4_u32_u8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// A window row's pixels of both planes under the tile: every read in flight before the first one is used (a tile is
+// latency-, not throughput-bound; left to itself the compiler waits for each pair of columns in turn)
+template <int NCOLS>
+__device__ __forceinline__ void ring_row(uint32_t (&av)[NCOLS], uint32_t (&bv)[NCOLS], const uint32_t *ar, const uint32_t *br)
+{
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+        av[c] = ar[c];
+        bv[c] = br[c];
+    }
+    // (the reads stay in front of this point, the arithmetic on what they return behind it)
+    static_assert(NCOLS % 8 == 0, "pinned eight at a time");
+    asm volatile("" : : : "memory");
+#pragma unroll
+    for (int c = 0; c < NCOLS; c += 8) {
+        asm volatile("" : "+v"(av[c]), "+v"(av[c + 1]), "+v"(av[c + 2]), "+v"(av[c + 3]), "+v"(av[c + 4]), "+v"(av[c + 5]),
+                          "+v"(av[c + 6]), "+v"(av[c + 7]));
+        asm volatile("" : "+v"(bv[c]), "+v"(bv[c + 1]), "+v"(bv[c + 2]), "+v"(bv[c + 3]), "+v"(bv[c + 4]), "+v"(bv[c + 5]),
+                          "+v"(bv[c + 6]), "+v"(bv[c + 7]));
+    }
 }
 
 // The clipped window of ring pixel (x, y), original coordinates -> canonical columns [ca, ce), rows [ra, re)
@@ -74,7 +103,7 @@ __device__ __forceinline__ RingWin ring_window(const RingArgs &g, int x, int y)
 // (pixel, part) scans 8 disparities in ascending order -- the reference's tie rule -- and
 // everything meets in one 64-bit LDS min per pixel.
 template <int MODE, int NCOLS> // NCOLS >= tile + 2 half - 1 window columns under a tile: 16 (half <= 4) or 24
-__global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtiles, int seg_top, int seg_bot, int xt_left,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) ws_ring_kernel(const RingArgs g, int xtiles, int seg_top, int seg_bot, int xt_left,
                                                       int xt_right, int seg_mid)
 {
     extern __shared__ uint32_t ring_lds[]; // the tile's strips of plane A and plane B
@@ -112,28 +141,64 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
     // the strips of both planes under the tile's windows go through LDS: A once, B per round of 256
     // disparities (columns c - d + boff for c in [CA, CE), d in [dblk, dtop])
     uint32_t *sA = ring_lds, *sB = ring_lds + nc * nr;
-    for (int i = tid; i < nc * nr; i += 256) {
-        const int r = i / nc, c = i - r * nc;
-        sA[i] = g.A[(size_t)(RA + r) * g.pitch_a + (CA + c + g.pad_a)]; // (the windows lie inside the image)
+    // (A strip's loads are all in flight before its first store, addresses clamped instead of branched around: a
+    // workgroup is alone on its SIMDs, and a load-store-load chain costs a trip to memory per element.  No divisions:
+    // A's rows are at most 32 columns -- a thread is (row tid / 32 + 8 k, column tid % 32) -- and B's at most
+    // 256 + 31: column tid of eight rows at a time, then the columns past 256 like A's.)
+    constexpr int kPasses = (NCOLS + 7) / 8;
+    const int c32 = tid & 31, r8 = tid >> 5;
+    if (nc * nr > 0) {
+        uint32_t v[kPasses];
+#pragma unroll
+        for (int k = 0; k < kPasses; ++k) {
+            const bool ok = c32 < nc && r8 + 8 * k < nr;
+            v[k] = g.A[(size_t)(RA + (ok ? r8 + 8 * k : 0)) * g.pitch_a + (CA + (ok ? c32 : 0) + g.pad_a)]; // (the windows lie inside the image)
+        }
+#pragma unroll
+        for (int k = 0; k < kPasses; ++k)
+            if (c32 < nc && r8 + 8 * k < nr) sA[(r8 + 8 * k) * nc + c32] = v[k];
     }
     if (tid < kRingTile * kRingTile) best[tid] = LLONG_MAX;
     for (int dblk = g.d_lo; dblk <= g.d_hi && nyc > 0; dblk += 256) {
         const int dtop = min(dblk + 255, g.d_hi);
         const int CB = CA - dtop + g.boff, WB = nc + (dtop - dblk);
         __syncthreads(); // (the previous round's readers are done with sB; first round: sA / best are written)
-        for (int i = tid; i < WB * nr; i += 256) {
-            const int r = i / WB, c = CB + (i - r * WB) + g.pad_b;
-            sB[i] = c >= 0 && c < g.pitch_b ? g.B[(size_t)(RA + r) * g.pitch_b + c] : 0u;
+        for (int rb = 0; rb < nr; rb += kRingBatch) {
+            uint32_t v[kRingBatch];
+            const int c = CB + tid + g.pad_b;
+            const bool in = tid < WB && c >= 0 && c < g.pitch_b;
+#pragma unroll
+            for (int k = 0; k < kRingBatch; ++k) {
+                const uint32_t px = g.B[(size_t)(RA + min(rb + k, nr - 1)) * g.pitch_b + (in ? c : 0)];
+                v[k] = in ? px : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kRingBatch; ++k)
+                if (rb + k < nr && tid < WB) sB[(rb + k) * WB + tid] = v[k];
+        }
+        if (WB > 256 && nr > 0) {
+            uint32_t v[kPasses];
+            const int cc = 256 + c32, c = CB + cc + g.pad_b;
+            const bool in = cc < WB && c >= 0 && c < g.pitch_b;
+#pragma unroll
+            for (int k = 0; k < kPasses; ++k) {
+                const uint32_t px = g.B[(size_t)(RA + min(r8 + 8 * k, nr - 1)) * g.pitch_b + (in ? c : 0)];
+                v[k] = in ? px : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kPasses; ++k)
+                if (cc < WB && r8 + 8 * k < nr) sB[(r8 + 8 * k) * WB + cc] = v[k];
         }
         __syncthreads();
         const int d = dblk + tid;
         // A0[r * nc + c] / B0[r * WB + c]: the planes at window row RA + r, window column CA + c (B shifted by d);
         // a thread beyond d_hi reads in-bounds garbage (clamped shift) that no candidate test accepts
         const uint32_t *A0 = sA, *B0 = sB + max(dtop - d, 0);
-        // the column sums stay in registers; everything below is unrolled over the NCOLS columns
-        // (clamped index: columns past nc repeat the last one and are never summed) so that a row's
-        // LDS reads are all in flight together -- the tile is latency-, not throughput-bound
-        int32_t sum[NCOLS];
+        // the column sums stay in registers; everything below is unrolled over the NCOLS columns at compile-time
+        // offsets from the row's start (one address per row and plane, the columns in the reads' offset fields).
+        // Columns past nc read whatever follows in LDS -- the next row, the other plane, the kRingSlack words
+        // behind the strips -- into sums that no pixel's column range reaches (ce <= nc).
+        uint32_t sum[NCOLS];
         int ra = 0, re = 0;
         for (int j = 0; j < nyc; ++j) {
             const int y = y0 + j;
@@ -141,35 +206,55 @@ __global__ void __launch_bounds__(256) ws_ring_kernel(const RingArgs g, int xtil
             const int r0 = wr.ra - RA, r1 = max(wr.re - RA, r0);
             // 1. column sums of the window rows [r0, r1)
             if (j == 0) {
+                if constexpr (MODE == 0) {
 #pragma unroll
-                for (int c = 0; c < NCOLS; ++c) sum[c] = 0;
-                for (int r = r0; r < r1; ++r) {
+                    for (int c = 0; c < NCOLS; ++c) sum[c] = 0;
+                    for (int r = r0; r < r1; ++r) {
+                        uint32_t av[NCOLS], bv[NCOLS];
+                        ring_row<NCOLS>(av, bv, A0 + r * nc, B0 + r * WB);
 #pragma unroll
-                    for (int c = 0; c < NCOLS; ++c) {
-                        const int cc = min(c, nc - 1);
-                        sum[c] += ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                        for (int c = 0; c < NCOLS; ++c) sum[c] = pix_sad(av[c], bv[c], sum[c]);
                     }
+                } else { // b.b and a.b on accumulators of their own: two instructions per pixel pair
+                    uint32_t ab[NCOLS];
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) sum[c] = ab[c] = 0;
+                    for (int r = r0; r < r1; ++r) {
+                        uint32_t av[NCOLS], bv[NCOLS];
+                        ring_row<NCOLS>(av, bv, A0 + r * nc, B0 + r * WB);
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c) {
+                            sum[c] = pix_dot<MODE == 2>(bv[c], bv[c], sum[c]);
+                            ab[c] = pix_dot<MODE == 2>(av[c], bv[c], ab[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c) sum[c] -= 2 * ab[c];
                 }
             } else {
                 for (int r = ra; r < r0; ++r) { // rows that left the window (at most one)
+                    uint32_t av[NCOLS], bv[NCOLS];
+                    ring_row<NCOLS>(av, bv, A0 + r * nc, B0 + r * WB);
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
-                        const int cc = min(c, nc - 1);
-                        sum[c] -= ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                        if constexpr (MODE == 0) sum[c] -= ring_dot0<MODE>(av[c], bv[c]);
+                        else sum[c] = sum[c] - ring_dot0<MODE>(bv[c], bv[c]) + 2 * ring_dot0<MODE>(av[c], bv[c]);
                     }
                 }
                 for (int r = re; r < r1; ++r) { // rows that entered it (at most one)
+                    uint32_t av[NCOLS], bv[NCOLS];
+                    ring_row<NCOLS>(av, bv, A0 + r * nc, B0 + r * WB);
 #pragma unroll
                     for (int c = 0; c < NCOLS; ++c) {
-                        const int cc = min(c, nc - 1);
-                        sum[c] += ring_px<MODE>(A0[r * nc + cc], B0[r * WB + cc]);
+                        if constexpr (MODE == 0) sum[c] = pix_sad(av[c], bv[c], sum[c]);
+                        else sum[c] = pix_dot<MODE == 2>(bv[c], bv[c], sum[c]) - 2 * ring_dot0<MODE>(av[c], bv[c]);
                     }
                 }
             }
             ra = r0; re = r1;
             // prefix sums over the columns, to LDS for the pixels' (run-time) column ranges
             {
-                int32_t acc = 0;
+                uint32_t acc = 0;
                 prefix[0][tid] = 0;
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c) {
@@ -245,7 +330,7 @@ hipError_t launch_ring(const Canon &c, Plane a, Plane b, const GenericArgs &skip
     if (blocks <= 0) return hipSuccess;
     dim3 grid((unsigned)blocks);
     const int side = kRingTile + 2 * g.half; // >= window columns and window rows under a tile
-    const size_t lds = (size_t)(side * side + side * (side + 255)) * sizeof(uint32_t);
+    const size_t lds = (size_t)(side * side + side * (side + 255) + kRingSlack) * sizeof(uint32_t);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, g, xtiles, seg_top, seg_bot, xt_left, xt_right, seg_mid); };
     const bool narrow = kRingTile + 2 * g.half - 1 <= 16;
     if (!g.ssd) narrow ? launch(ws_ring_kernel<0, 16>) : launch(ws_ring_kernel<0, kRingCols>);
