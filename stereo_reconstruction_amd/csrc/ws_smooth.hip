@@ -127,6 +127,7 @@ __device__ __forceinline__ uint8_t smooth_code(long long c0, long long c1, bool 
 }
 
 constexpr int kBoxRows = 32, kBoxMaxW = 16; // tile rows; widest / tallest right-view marching window
+constexpr int kBoxBatch = 4;                // rows a thread has in flight while a tile's pixel terms are staged
 
 template <bool SSD, bool CENTRED>
 __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const PreparePlanesArgs g)
@@ -139,21 +140,50 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
     const int xt = g.ox0 + blockIdx.x * 64, y0 = g.oy0 + blockIdx.y * kBoxRows;
     const int y1 = min(y0 + kBoxRows, g.oy1);
     const int nrows = (y1 - y0) + g.wh - 1, ncols = 64 + g.ww - 1;
-    // (1) per pixel: cost against the d = 0 partner, and a^2
-    for (int k = ty; k < nrows; k += 4) {
-        const size_t row = (size_t)(y0 + g.wy0 + k);
-        for (int cx = tx; cx < ncols; cx += 64) {
-            const int ca = xt + g.wx0 + cx + g.pad_a, cb = xt + g.wx0 + cx + g.boff + g.pad_b;
-            const uint32_t a = ca >= 0 && ca < g.pitch_a ? g.A[row * g.pitch_a + ca] : 0u;
-            const uint32_t b = cb >= 0 && cb < g.pitch_b ? g.B[row * g.pitch_b + cb] : 0u;
-            if constexpr (SSD) {
-                const uint32_t aa = pix_dot<CENTRED>(a, a, 0u);
-                e0[k][cx] = aa + pix_dot<CENTRED>(b, b, 0u) - 2u * pix_dot<CENTRED>(a, b, 0u); // (a-b)^2 >= 0
-                ea[k][cx] = aa;
-            } else {
-                e0[k][cx] = pix_sad(a, b, 0u);
+    // (1) per pixel: cost against the d = 0 partner, and a^2.  A wave takes every 4th row, kBoxBatch of them at a
+    // time with all their loads in flight (clamped addresses, no branches): with one or two workgroups on a CU the
+    // tile is bound by the trips to memory, not by their width.
+    for (int cx = tx; cx < ncols; cx += 64) {
+        const int ca = xt + g.wx0 + cx + g.pad_a, cb = xt + g.wx0 + cx + g.boff + g.pad_b;
+        const bool ina = ca >= 0 && ca < g.pitch_a, inb = cb >= 0 && cb < g.pitch_b;
+        for (int k0 = ty; k0 < nrows; k0 += 4 * kBoxBatch) {
+            uint32_t a[kBoxBatch], b[kBoxBatch];
+#pragma unroll
+            for (int i = 0; i < kBoxBatch; ++i) {
+                const size_t row = (size_t)(y0 + g.wy0 + min(k0 + 4 * i, nrows - 1));
+                a[i] = g.A[row * g.pitch_a + (ina ? ca : 0)];
+                b[i] = g.B[row * g.pitch_b + (inb ? cb : 0)];
+            }
+#pragma unroll
+            for (int i = 0; i < kBoxBatch; ++i) {
+                const int k = k0 + 4 * i;
+                if (k >= nrows) break;
+                const uint32_t pa = ina ? a[i] : 0u, pb = inb ? b[i] : 0u;
+                if constexpr (SSD) {
+                    const uint32_t aa = pix_dot<CENTRED>(pa, pa, 0u);
+                    e0[k][cx] = aa + pix_dot<CENTRED>(pb, pb, 0u) - 2u * pix_dot<CENTRED>(pa, pb, 0u); // (a-b)^2 >= 0
+                    ea[k][cx] = aa;
+                } else {
+                    e0[k][cx] = pix_sad(pa, pb, 0u);
+                }
             }
         }
+    }
+    // (what the decisions of stage 3 read from memory: asked for now, used after two barriers)
+    constexpr int seg = kBoxRows / 4;
+    const int x = xt + tx; // canonical (mirrored) column
+    const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
+    const int xo = g.wa - 1 - x; // original column
+    const bool mine = x < g.ox1 && ya < yb;
+    uint32_t apx[seg];
+    int32_t cst[seg];
+    float prev[seg];
+#pragma unroll
+    for (int i = 0; i < seg; ++i) {
+        const int y = mine ? min(ya + i, yb - 1) : g.oy0, xx = mine ? x : g.ox0, xxo = g.wa - 1 - xx;
+        apx[i] = g.A[(size_t)y * g.pitch_a + xx + g.pad_a];
+        cst[i] = g.cost[(size_t)y * g.cost_pitch + xxo];
+        prev[i] = g.out[(size_t)y * g.out_pitch + xxo];
     }
     __syncthreads();
     // (2) horizontal window sums
@@ -169,11 +199,7 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
     }
     __syncthreads();
     // (3) vertical sliding sums and the decision
-    const int x = xt + tx; // canonical (mirrored) column
-    const int seg = kBoxRows / 4;
-    const int ya = y0 + ty * seg, yb = min(ya + seg, y1);
-    if (x >= g.ox1 || ya >= yb) return;
-    const int xo = g.wa - 1 - x; // original column
+    if (!mine) return;
     uint32_t c0 = 0, sa = 0;
     for (int k = 0; k < g.wh; ++k) {
         c0 += h0[ya - y0 + k][tx];
@@ -181,19 +207,22 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
     }
     const double area = (double)(g.ww * g.wh);
     const int xb0 = x + g.boff; // target centre of d = 0
-    for (int y = ya; y < yb; ++y) {
+#pragma unroll
+    for (int i = 0; i < seg; ++i) {
+        const int y = ya + i;
+        if (y >= yb) break;
         float *o = g.out + (size_t)y * g.out_pitch + xo;
         uint8_t code = kSelFixed;
         float val = 0.0f;
-        if (g.A[(size_t)y * g.pitch_a + x + g.pad_a] != (CENTRED ? kCentre : 0u)) {
+        if (apx[i] != (CENTRED ? kCentre : 0u)) {
             if (!(g.d_hi >= 0 && xb0 >= g.b_lo)) {
                 val = -(float)xo; // no candidate at all
             } else {
                 // the search's d >= 1 winner -- or, when d = 0 is the only candidate, its fallback -x --
                 // stays unless the recurrence says 0
                 const bool has_d1 = g.d_hi >= 1 && xb0 - 1 >= g.b_lo;
-                val = *o;
-                const long long c1 = has_d1 ? (long long)g.cost[(size_t)y * g.cost_pitch + xo] + (SSD ? (long long)sa : 0LL) : 0LL;
+                val = prev[i];
+                const long long c1 = has_d1 ? (long long)cst[i] + (SSD ? (long long)sa : 0LL) : 0LL;
                 code = smooth_code<SSD>((long long)c0, c1, has_d1, area, g.s);
             }
         }
@@ -237,15 +266,26 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
             const uint32_t *pa0 = g.A + (size_t)(y - up) * g.pitch_a + ca + g.pad_a;
             const uint32_t *pb0 = g.B + (size_t)(y - up) * g.pitch_b + ca + g.boff + g.pad_b;
             uint32_t aa = 0, bb = 0, ab = 0; // a lane sees at most (16 * 16) / 64 pixels: 32 bits hold
-            for (int i = lane; i < ww * wh; i += 64) {
-                const int r = i / ww, c = i - r * ww;
-                const uint32_t a = pa0[(size_t)r * g.pitch_a + c], b = pb0[(size_t)r * g.pitch_b + c];
+            // the window is at most 16 x 16 (launch_smooth): lane = (row % 4, column), four rows each, their loads in
+            // flight together (clamped, not branched around: the wave waits for memory once, not four times)
+            const int c = lane & 15, r4 = lane >> 4;
+            uint32_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = c < ww && r4 + 4 * i < wh;
+                const int r = ok ? r4 + 4 * i : 0, cc = ok ? c : 0;
+                a[i] = pa0[(size_t)r * g.pitch_a + cc];
+                b[i] = pb0[(size_t)r * g.pitch_b + cc];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!(c < ww && r4 + 4 * i < wh)) continue;
                 if constexpr (SSD) {
-                    aa = pix_dot<CENTRED>(a, a, aa);
-                    bb = pix_dot<CENTRED>(b, b, bb);
-                    ab = pix_dot<CENTRED>(a, b, ab);
+                    aa = pix_dot<CENTRED>(a[i], a[i], aa);
+                    bb = pix_dot<CENTRED>(b[i], b[i], bb);
+                    ab = pix_dot<CENTRED>(a[i], b[i], ab);
                 } else {
-                    ab = pix_sad(a, b, ab);
+                    ab = pix_sad(a[i], b[i], ab);
                 }
             }
             long long c0, sa = 0;
