@@ -914,6 +914,22 @@ __device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch
 // lanes replay the same decision.  A step has ~100 instructions fewer (of ~700 at 7 x 7), the chain of steps is 5 %
 // longer (more, shorter bands): 3.22 -> 3.12 ms at 7 x 7, 5.05 -> 4.74 ms at 17 x 17 (profiles/r04/left_smooth.txt) --
 // a step's time is mostly NOT its instruction count (see there for what else was tried).
+#ifdef WS_BAND_STAMPS
+// Development build only (tools/band_stamps.py): s_memtime at five points of a step, steps [kStampStep0, +kStampSteps) of
+// every band; read back through ws_debug_band_stamps.  Each stamp waits for the scalar unit's counter (lgkmcnt(0)), so a
+// stamped step is a little longer than a plain one.
+constexpr int kStampBands = 32, kStampStep0 = 300, kStampSteps = 128, kStampPoints = 5;
+__device__ unsigned long long ws_band_stamps[kStampBands][kStampSteps][kStampPoints];
+#define WS_STAMP(p)                                                                                        \
+    do {                                                                                                   \
+        if (band < kStampBands && k >= kStampStep0 && k < kStampStep0 + kStampSteps) {                     \
+            const unsigned long long now_ = __builtin_readcyclecounter();                                  \
+            if (lane == 0) ws_band_stamps[band][k - kStampStep0][p] = now_;                                \
+        }                                                                                                  \
+    } while (0)
+#else
+#define WS_STAMP(p) do { } while (0)
+#endif
 constexpr int kBandLanes = 64;            // one wave per band
 constexpr int kBandRows = kBandLanes / 2; // rows per band: two lanes per row
 constexpr unsigned long long kEdgeNone = ~0ull;
@@ -927,7 +943,11 @@ constexpr int kBandFill = 5;  // steps a window column is requested ahead of its
 // neighbour's value slid down from the row above, the left neighbour's value slid along the row -- are then read
 // from LDS at the TOP of the decision, for every lane, whether or not it will need them (8 BS registers): one wave per
 // CU has nothing else to hide an LDS round trip behind, and a step used to make fifteen to twenty of them in a row.
-template <int MODE, int BS = 0> // MODE -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
+// TW (with BS > 0): a second, ROW-major copy of both windows (+ BS mirrored columns behind the circular ones), so that the
+// down slide's window rows are consecutive dwords like the right slide's window columns are in the column-major copy:
+// every line of the two sums is then read at compile-time offsets from ONE address -- no stride, no wrap-around test per
+// element (those were two thirds of the sums' instructions; profiles/r04/left_smooth.txt, 6.).
+template <int MODE, int BS = 0, bool TW = false> // MODE -1: window lines from global memory; 0 SAD / 1 SSD / 2 SSD centred: from the LDS windows
 __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const SmoothLeftArgs g, const uint32_t *__restrict__ top,
                                                                          int top_pitch, unsigned long long *edge, int edge_pitch,
                                                                          unsigned int *ctrl, int cwa, int cwb)
@@ -1000,6 +1020,40 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
             lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, lane);
         }
     }
+    // the row-major copies (TW): element (plane column c, LDS row r) at [r * tw + phys(c)], and again at [.. + cw] for
+    // phys(c) < BS.  A column is read from memory by ordinary loads (lane = LDS row) in the step that requests its
+    // LDS-DMA, and stored at the top of the next step: four steps before its first use.
+    static_assert(!TW || (BS > 0 && MODE >= 0), "the row-major copy serves the compile-time sliding sums");
+    constexpr int TB = TW ? BS : 0;
+    const int twa = (cwa + TB + 1) & ~1, twb = (cwb + TB + 1) & ~1; // even: lanes one row down, one column left -> odd dword distance
+    uint32_t *const tA = reinterpret_cast<uint32_t *>(ws_smem4) + (size_t)(cwa + cwb) * (lds_rows + 1);
+    uint32_t *const tB = tA + (size_t)twa * lds_rows;
+    const int t_lane = min(lane, lds_rows - 1); // (lanes past the last LDS row repeat it: same value, same place)
+    const uint32_t *const t_row_a = g.A + (size_t)min(max(win.row0 + t_lane, 0), g.h1 - 1) * g.pitch_a; // (clamped like lds_fill_column)
+    const uint32_t *const t_row_b = g.B + (size_t)min(max(win.row0 + t_lane, 0), g.h2 - 1) * g.pitch_b;
+    uint32_t *const t_lane_a = tA + t_lane * twa, *const t_lane_b = tB + t_lane * twb;
+    auto t_load = [&](const uint32_t *row, int pitch, int col) -> uint32_t { return row[min(max(col, 0), pitch - 1)]; };
+    auto t_store = [&](uint32_t *t, int cw, int phys, uint32_t v) {
+        t[phys] = v;
+        if (phys < TB) t[phys + cw] = v; // (uniform)
+    };
+    // (per-lane constants of the sliding sums' addresses; r_in / r_out / r_col: the LDS rows of the window row that enters,
+    // the one that leaves, the window's first)
+    const int tw_r_in = y + half - win.row0, tw_r_out = y - 1 - half - win.row0, tw_r_col = y - half - win.row0;
+    const int tw_ta = (int)(tA - win.A), tw_tb = (int)(tB - win.A), tw_cb = (int)(win.B - win.A);
+    const int tw_col_in = role ? half : -half, tw_col_out = role ? -1 - half : -half;
+    const int tw_mul = role ? win.rp : 1;
+    const int tw_a_in = role ? tw_r_col : tw_ta + tw_r_in * twa, tw_a_out = role ? tw_r_col : tw_ta + tw_r_out * twa;
+    const int tw_b_in = role ? tw_cb + tw_r_col : tw_tb + tw_r_in * twb, tw_b_out = role ? tw_cb + tw_r_col : tw_tb + tw_r_out * twb;
+    uint32_t tva = 0, tvb = 0; // the column requested in the previous step ...
+    int tcol = -1;             // ... (image column; -1: none)
+    if constexpr (TW) {
+        for (int c = 0; c < 2 * half + kBandFill; ++c) {
+            t_store(t_lane_a, cwa, win.pa(c + g.pad_a), t_load(t_row_a, g.pitch_a, c + g.pad_a));
+            t_store(t_lane_b, cwb, win.pb(c + g.pad_b), t_load(t_row_b, g.pitch_b, c + g.pad_b));
+        }
+    }
+    const int slack = cwa - (2 * half + kBandRows + 2 + kBandFill); // columns the windows keep behind the last one any lane reads
     // window cost of candidate d at (x, y) from the cost at (x-1, y), from the cost at (x, y-1), or summed whole
     auto cost_slide = [&](uint32_t c_prev, int x, int d) -> uint32_t {
         if constexpr (MODE >= 0) {
@@ -1063,16 +1117,26 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
         const int xs = k - t;
         const bool in = k >= 0 && row_ok && xs >= 0 && xs < iw;
         const int x = half + xs;
+        WS_STAMP(0);
         flush_result();
         if constexpr (MODE >= 0) {
             if (k >= 0) {
-                // the windows' lowest columns are k - kBandRows - 32 and that - max_d (image columns; 32 columns of slack as ever)
-                const int lo_a = max(k - kBandRows - 32, 0) + g.pad_a, lo_b = max(k - kBandRows - 32 - g.max_d, 0) + g.pad_b;
+                // the windows' lowest columns are k - kBandRows - slack and that - max_d (image columns)
+                const int lo_a = max(k - kBandRows - slack, 0) + g.pad_a, lo_b = max(k - kBandRows - slack - g.max_d, 0) + g.pad_b;
                 if (lo_a >= win.wa + win.cwa) win.wa += win.cwa;
                 if (lo_b >= win.wb + win.cwb) win.wb += win.cwb;
                 const int cn = k + 2 * half + kBandFill; // first read at step k + kBandFill
                 lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, lane);
                 lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, lane);
+                if constexpr (TW) {
+                    if (tcol >= 0) {
+                        t_store(t_lane_a, cwa, win.pa(tcol + g.pad_a), tva);
+                        t_store(t_lane_b, cwb, win.pb(tcol + g.pad_b), tvb);
+                    }
+                    tva = t_load(t_row_a, g.pitch_a, cn + g.pad_a);
+                    tvb = t_load(t_row_b, g.pitch_b, cn + g.pad_b);
+                    tcol = cn;
+                }
             }
         }
         // this step's inputs leave their slot, the inputs of step k + kBandDepth take it
@@ -1093,6 +1157,7 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
             if (band > 0 && t == 0) sl.aw = __hip_atomic_load(&edge_in[xc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (k < 0) return; // (uniform)
+        WS_STAMP(1);
         // the upper neighbour (y-1, x): the lane above finished it in the previous step
         // (wave_shr:1 -- one DPP move each; __shfl_up goes through the LDS crossbar and its latency)
         // (the row above is two lanes up: both of its lanes hold the same result)
@@ -1128,6 +1193,7 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
         // x - 1 - half out: consecutive dwords of one column).  One instruction stream: element i of a line sits at
         // base + i * stride, minus the window's span once it runs past the window's end.
         constexpr int NB = BS > 0 ? BS : 1;
+        WS_STAMP(2);
         uint32_t pre_down = 0, pre_right = 0; // c_above slid down to (x, y) / lcost slid right to (x, y): valid if those were
         if (MODE >= 0 && BS > 0 && other_can_win) { // (uniform)
             const int xq = half + min(max(xs, 1), iw - 1);                  // (lanes outside their row read somewhere harmless)
@@ -1136,6 +1202,26 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
             const int span_a = win.cwa * win.rp, span_b = win.cwb * win.rp;
             // first elements (dword offsets inside the windows) and strides
             int a_in, b_in, a_out, b_out, stride;
+            uint32_t va_in[NB], vb_in[NB], va_out[NB], vb_out[NB];
+            if constexpr (TW) {
+                // One expression for both roles (a branch per role runs both sides, one after the other): the column a line
+                // starts in differs by a per-lane constant, its physical column is scaled by rp (column-major copy, right
+                // slide) or by 1 (row-major copy, down slide), the rest of the offset -- which copy, which row -- never
+                // changes (tw_* below, dword offsets from win.A: the copies lie one behind the other).
+                const int d = role ? dl : du;
+                const int ci = xq + tw_col_in, co = xq + tw_col_out;
+                a_in = __mul24(win.pa(ci + g.pad_a), tw_mul) + tw_a_in;
+                b_in = __mul24(win.pb(ci - d + g.pad_b), tw_mul) + tw_b_in;
+                a_out = __mul24(win.pa(co + g.pad_a), tw_mul) + tw_a_out;
+                b_out = __mul24(win.pb(co - d + g.pad_b), tw_mul) + tw_b_out;
+                (void)stride; (void)span_a; (void)span_b; (void)r_in; (void)r_out; (void)r_col;
+                const uint32_t *pai = win.A + a_in, *pbi = win.A + b_in, *pao = win.A + a_out, *pbo = win.A + b_out;
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    va_in[i] = pai[i]; vb_in[i] = pbi[i];
+                    va_out[i] = pao[i]; vb_out[i] = pbo[i];
+                }
+            } else {
             if (role == 0) {
                 a_in = win.oa(xq - half + g.pad_a) + r_in;  b_in = win.ob(xq - half - du + g.pad_b) + r_in;
                 a_out = a_in + (r_out - r_in);              b_out = b_in + (r_out - r_in);
@@ -1147,7 +1233,6 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
             }
             // (a column's dwords never wrap; a row's elements do when their column index passes the window's end: then the
             // offset is at least `span` -- columns are rp dwords apart and the rows add less than rp)
-            uint32_t va_in[NB], vb_in[NB], va_out[NB], vb_out[NB];
 #pragma unroll
             for (int i = 0; i < BS; ++i) {
                 va_in[i] = win.A[a_in]; vb_in[i] = win.B[b_in];
@@ -1158,11 +1243,34 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
                 if (b_in >= span_b) b_in -= span_b;
                 if (b_out >= span_b) b_out -= span_b;
             }
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): ONE wait for all the lines instead of one per dword
             uint32_t acc = role == 0 ? c_above : lcost;
+            if constexpr (TW) {
+                // the lines' sums on accumulators of their own: sum (a-b)^2 = sum a.a + sum b.b - 2 sum a.b, every product one
+                // accumulating v_dot4 (a fresh (a-b)^2 per pixel pair costs a v_mov of the 0 per product and two additions)
+                constexpr int M = MODE >= 0 ? MODE : 0;
+                uint32_t in0 = 0, in1 = 0, in2 = 0, out0 = 0, out1 = 0, out2 = 0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if constexpr (M == 0) {
+                        in0 = pix_sad(va_in[i], vb_in[i], in0);
+                        out0 = pix_sad(va_out[i], vb_out[i], out0);
+                    } else {
+                        in0 = pix_dot<M == 2>(va_in[i], va_in[i], in0);
+                        in1 = pix_dot<M == 2>(vb_in[i], vb_in[i], in1);
+                        in2 = pix_dot<M == 2>(va_in[i], vb_in[i], in2);
+                        out0 = pix_dot<M == 2>(va_out[i], va_out[i], out0);
+                        out1 = pix_dot<M == 2>(vb_out[i], vb_out[i], out1);
+                        out2 = pix_dot<M == 2>(va_out[i], vb_out[i], out2);
+                    }
+                }
+                acc += (in0 + in1 - 2u * in2) - (out0 + out1 - 2u * out2);
+            } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 acc += left_pix_cost<(MODE >= 0 ? MODE : 0)>(va_in[i], vb_in[i]) - left_pix_cost<(MODE >= 0 ? MODE : 0)>(va_out[i], vb_out[i]);
+            }
             // the pixel's other lane has the other sum: quad_perm [1, 0, 3, 2]
             const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xb1, 0xf, 0xf, false);
             pre_down = role == 0 ? acc : other;
@@ -1171,6 +1279,7 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
         auto pre_slide_down = [&](uint32_t) -> uint32_t { return pre_down; };
         auto pre_slide = [&](uint32_t) -> uint32_t { return pre_right; };
         constexpr bool PRE = MODE >= 0 && BS > 0;
+        WS_STAMP(3);
         if (in) {
             float v;
             if (e0.x == kTopNone) {
@@ -1242,6 +1351,7 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
             cprev = lknown ? lcost : kTopNone;
             store_x = x; // (written at the top of the next step)
         }
+        WS_STAMP(4);
     };
     static_assert(kBandDepth == 3, "the loop below is unrolled by hand");
     for (int k = -kBandDepth; k < nsteps; k += kBandDepth) {
@@ -1328,30 +1438,46 @@ hipError_t launch_smooth_left(const GenericArgs &g, double s, uint32_t *top3, co
     // the planes' moving windows in LDS when the marching kernel left its planes behind and they fit
     const int cwa = 2 * half + kBandRows + 34 + kBandFill, cwb = g.max_d + 2 * half + kBandRows + 34 + kBandFill, rp = kBandRows + 2 * half + 2;
     const size_t lds = (size_t)(cwa + cwb) * rp * sizeof(uint32_t);
-    auto launch = [&](auto kernel, size_t bytes) -> hipError_t {
+    // ... and, for the block sizes with a compile-time form, their row-major copies behind them (4 columns of slack
+    // instead of 32, or 17 x 17 at D = 200 would not fit both)
+    const int bs = g.block_size;
+    const int cwa_t = 2 * half + kBandRows + 6 + kBandFill, cwb_t = g.max_d + cwa_t;
+    const size_t lds_t = (size_t)(cwa_t + cwb_t) * rp * sizeof(uint32_t) +
+                         (size_t)(((cwa_t + bs + 1) & ~1) + ((cwb_t + bs + 1) & ~1)) * (rp - 1) * sizeof(uint32_t);
+    static const bool no_tw = [] {
+        const char *e = getenv("WS_LEFT_TW"); // development knob: 0 = without the row-major copies
+        return e && atoi(e) == 0;
+    }();
+    // (only the factors below 1 run the sliding sums at all: above, an unlisted neighbour value never wins)
+    const bool tw = !no_tw && !(s >= 1.0) && lds_t <= 158 * 1024 && rp - 1 <= kBandLanes;
+    auto launch = [&](auto kernel, size_t bytes, int ca, int cb) -> hipError_t {
         if (bytes > 48 * 1024) {
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (err != hipSuccess) return err;
         }
-        hipLaunchKernelGGL(kernel, dim3(nbands), dim3(kBandLanes), bytes, st, a, top3, g.w1, edge, (int)pitch, ctrl, cwa, cwb);
+        hipLaunchKernelGGL(kernel, dim3(nbands), dim3(kBandLanes), bytes, st, a, top3, g.w1, edge, (int)pitch, ctrl, ca, cb);
         return hipGetLastError();
     };
     if (canon && lds <= 152 * 1024 && 2 * half + 1 + kBandRows <= 128) {
         // (block sizes of the BASELINE configs and of the reference's own call get the compile-time form)
+#define WS_LEFT_BS_ONE(MODE, N)                                                                       \
+        case N: return tw ? launch(ws_smooth_left_bands_kernel<MODE, N, true>, lds_t, cwa_t, cwb_t)  \
+                          : launch(ws_smooth_left_bands_kernel<MODE, N>, lds, cwa, cwb);
 #define WS_LEFT_BS(MODE)                                                                              \
         switch (g.block_size) {                                                                       \
-        case 5: return launch(ws_smooth_left_bands_kernel<MODE, 5>, lds);                             \
-        case 7: return launch(ws_smooth_left_bands_kernel<MODE, 7>, lds);                             \
-        case 9: return launch(ws_smooth_left_bands_kernel<MODE, 9>, lds);                             \
-        case 17: return launch(ws_smooth_left_bands_kernel<MODE, 17>, lds);                           \
-        default: return launch(ws_smooth_left_bands_kernel<MODE, 0>, lds);                            \
+        WS_LEFT_BS_ONE(MODE, 5)                                                                       \
+        WS_LEFT_BS_ONE(MODE, 7)                                                                       \
+        WS_LEFT_BS_ONE(MODE, 9)                                                                       \
+        WS_LEFT_BS_ONE(MODE, 17)                                                                      \
+        default: return launch(ws_smooth_left_bands_kernel<MODE, 0>, lds, cwa, cwb);                  \
         }
         if (!a.ssd) { WS_LEFT_BS(0) }
         if (a.centred) { WS_LEFT_BS(2) }
         WS_LEFT_BS(1)
 #undef WS_LEFT_BS
+#undef WS_LEFT_BS_ONE
     }
-    return launch(ws_smooth_left_bands_kernel<-1>, 0);
+    return launch(ws_smooth_left_bands_kernel<-1>, 0, cwa, cwb);
 }
 
 // ---- bit-parallel form for 0 <= smoothFactor <= 1 -------------------------------------------
@@ -1674,3 +1800,11 @@ hipError_t launch_smooth(const GenericArgs &g, double s, uint8_t *sel, int sel_p
 }
 
 } // namespace wsamd
+
+#ifdef WS_BAND_STAMPS
+extern "C" int ws_debug_band_stamps(unsigned long long *dst, int *bands, int *steps, int *points)
+{
+    *bands = wsamd::kStampBands; *steps = wsamd::kStampSteps; *points = wsamd::kStampPoints;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wsamd::ws_band_stamps), sizeof(wsamd::ws_band_stamps));
+}
+#endif
