@@ -985,6 +985,72 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
     uint32_t cprev = kTopNone;   // ... and that value's window cost there (kTopNone: not known)
     bool gave_up = false;
 
+    // the LDS windows (MODE >= 0): image columns [0, 2 half + kBandFill) before the first step, then one per step
+    LeftLds win{};
+    const int lds_rows = kBandRows + 2 * half + 1;
+    if constexpr (MODE >= 0) {
+        win.rp = lds_rows + 1; // even
+        win.cwa = cwa; win.cwb = cwb;
+        win.A = reinterpret_cast<uint32_t *>(ws_smem4);
+        win.B = win.A + (size_t)cwa * win.rp;
+        win.row0 = band * kBandRows - 1; // = (the band's first row) - half - 1
+        win.wa = (g.pad_a / cwa) * cwa; win.wb = (g.pad_b / cwb) * cwb;
+        if constexpr (!TW) { // (TW: both copies are written from registers, below)
+            for (int c = 0; c < 2 * half + kBandFill; ++c) {
+                lds_fill_column(g.A, g.pitch_a, g.h1, c + g.pad_a, win.A + win.pa(c + g.pad_a) * win.rp, win.row0, lds_rows, lane);
+                lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, lane);
+            }
+        }
+    }
+    // the row-major copies (TW): element (plane column c, LDS row r) at [r * tw + phys(c)], and again at [.. + cw] for
+    // phys(c) < BS.  With them a column comes from memory by an ordinary load (lane = LDS row) kBandFill steps before
+    // its first use and goes to BOTH copies at the top of the next step (no LDS-DMA: the value is in a register anyway,
+    // and a store is cheaper than the M0 dance).
+    static_assert(!TW || (BS > 0 && MODE >= 0), "the row-major copy serves the compile-time sliding sums");
+    constexpr int TB = TW ? BS : 0;
+    const int twa = (cwa + TB + 1) & ~1, twb = (cwb + TB + 1) & ~1; // even: lanes one row down, one column left -> odd dword distance
+    uint32_t *const tA = reinterpret_cast<uint32_t *>(ws_smem4) + (size_t)(cwa + cwb) * (lds_rows + 1);
+    uint32_t *const tB = tA + (size_t)twa * lds_rows;
+    const int t_lane = min(lane, lds_rows - 1); // (lanes past the last LDS row repeat it: same value, same place)
+    const uint32_t *const t_row_a = g.A + (size_t)min(max(win.row0 + t_lane, 0), g.h1 - 1) * g.pitch_a; // (clamped like lds_fill_column)
+    const uint32_t *const t_row_b = g.B + (size_t)min(max(win.row0 + t_lane, 0), g.h2 - 1) * g.pitch_b;
+    uint32_t *const t_lane_a = tA + t_lane * twa, *const t_lane_b = tB + t_lane * twb;
+    auto t_load = [&](const uint32_t *row, int pitch, int col) -> uint32_t { return row[min(max(col, 0), pitch - 1)]; };
+    uint32_t *const c_lane_a = win.A + t_lane, *const c_lane_b = win.B + t_lane; // (the column-major copies: [phys * rp + row])
+    auto t_store = [&](uint32_t *t, uint32_t *cm, int cw, int phys, uint32_t v) {
+        cm[__mul24(phys, win.rp)] = v;
+        t[phys] = v;
+        if (phys < TB) t[phys + cw] = v; // (uniform)
+    };
+    // (per-lane constants of the sliding sums' addresses; r_in / r_out / r_col: the LDS rows of the window row that enters,
+    // the one that leaves, the window's first)
+    const int tw_r_in = y + half - win.row0, tw_r_out = y - 1 - half - win.row0, tw_r_col = y - half - win.row0;
+    const int tw_ta = (int)(tA - win.A), tw_tb = (int)(tB - win.A), tw_cb = (int)(win.B - win.A);
+    const int tw_col_in = role ? half : -half, tw_col_out = role ? -1 - half : -half;
+    const int tw_mul = role ? win.rp : 1;
+    const int tw_a_in = role ? tw_r_col : tw_ta + tw_r_in * twa, tw_a_out = role ? tw_r_col : tw_ta + tw_r_out * twa;
+    const int tw_b_in = role ? tw_cb + tw_r_col : tw_tb + tw_r_in * twb, tw_b_out = role ? tw_cb + tw_r_col : tw_tb + tw_r_out * twb;
+    uint32_t tva = 0, tvb = 0; // the column requested in the previous step ...
+    int tcol = -1;             // ... (image column; -1: none)
+    if constexpr (TW) {
+        for (int c0 = 0; c0 < 2 * half + kBandFill; c0 += 4) { // (four columns' loads in flight)
+            uint32_t va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = t_load(t_row_a, g.pitch_a, c0 + i + g.pad_a);
+                vb[i] = t_load(t_row_b, g.pitch_b, c0 + i + g.pad_b);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i >= 2 * half + kBandFill) break; // (uniform)
+                t_store(t_lane_a, c_lane_a, cwa, win.pa(c0 + i + g.pad_a), va[i]);
+                t_store(t_lane_b, c_lane_b, cwb, win.pb(c0 + i + g.pad_b), vb[i]);
+            }
+        }
+    }
+    const int slack = cwa - (2 * half + kBandRows + 2 + kBandFill); // columns the windows keep behind the last one any lane reads
+    // (the windows' first columns are on their way or in place before the band waits for its turn: they are the caller's
+    // images, not the band above's results)
     // A band starts once the band above is kBandLag columns into its last row: from then on both run the same
     // program at the same pace, and a hand-off word asked for kBandDepth steps early has been written by then.
     if (band > 0) {
@@ -1005,55 +1071,6 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
         }
     }
 
-    // the LDS windows (MODE >= 0): image columns [0, 2 half + kBandFill) before the first step, then one per step
-    LeftLds win{};
-    const int lds_rows = kBandRows + 2 * half + 1;
-    if constexpr (MODE >= 0) {
-        win.rp = lds_rows + 1; // even
-        win.cwa = cwa; win.cwb = cwb;
-        win.A = reinterpret_cast<uint32_t *>(ws_smem4);
-        win.B = win.A + (size_t)cwa * win.rp;
-        win.row0 = band * kBandRows - 1; // = (the band's first row) - half - 1
-        win.wa = (g.pad_a / cwa) * cwa; win.wb = (g.pad_b / cwb) * cwb;
-        for (int c = 0; c < 2 * half + kBandFill; ++c) {
-            lds_fill_column(g.A, g.pitch_a, g.h1, c + g.pad_a, win.A + win.pa(c + g.pad_a) * win.rp, win.row0, lds_rows, lane);
-            lds_fill_column(g.B, g.pitch_b, g.h2, c + g.pad_b, win.B + win.pb(c + g.pad_b) * win.rp, win.row0, lds_rows, lane);
-        }
-    }
-    // the row-major copies (TW): element (plane column c, LDS row r) at [r * tw + phys(c)], and again at [.. + cw] for
-    // phys(c) < BS.  A column is read from memory by ordinary loads (lane = LDS row) in the step that requests its
-    // LDS-DMA, and stored at the top of the next step: four steps before its first use.
-    static_assert(!TW || (BS > 0 && MODE >= 0), "the row-major copy serves the compile-time sliding sums");
-    constexpr int TB = TW ? BS : 0;
-    const int twa = (cwa + TB + 1) & ~1, twb = (cwb + TB + 1) & ~1; // even: lanes one row down, one column left -> odd dword distance
-    uint32_t *const tA = reinterpret_cast<uint32_t *>(ws_smem4) + (size_t)(cwa + cwb) * (lds_rows + 1);
-    uint32_t *const tB = tA + (size_t)twa * lds_rows;
-    const int t_lane = min(lane, lds_rows - 1); // (lanes past the last LDS row repeat it: same value, same place)
-    const uint32_t *const t_row_a = g.A + (size_t)min(max(win.row0 + t_lane, 0), g.h1 - 1) * g.pitch_a; // (clamped like lds_fill_column)
-    const uint32_t *const t_row_b = g.B + (size_t)min(max(win.row0 + t_lane, 0), g.h2 - 1) * g.pitch_b;
-    uint32_t *const t_lane_a = tA + t_lane * twa, *const t_lane_b = tB + t_lane * twb;
-    auto t_load = [&](const uint32_t *row, int pitch, int col) -> uint32_t { return row[min(max(col, 0), pitch - 1)]; };
-    auto t_store = [&](uint32_t *t, int cw, int phys, uint32_t v) {
-        t[phys] = v;
-        if (phys < TB) t[phys + cw] = v; // (uniform)
-    };
-    // (per-lane constants of the sliding sums' addresses; r_in / r_out / r_col: the LDS rows of the window row that enters,
-    // the one that leaves, the window's first)
-    const int tw_r_in = y + half - win.row0, tw_r_out = y - 1 - half - win.row0, tw_r_col = y - half - win.row0;
-    const int tw_ta = (int)(tA - win.A), tw_tb = (int)(tB - win.A), tw_cb = (int)(win.B - win.A);
-    const int tw_col_in = role ? half : -half, tw_col_out = role ? -1 - half : -half;
-    const int tw_mul = role ? win.rp : 1;
-    const int tw_a_in = role ? tw_r_col : tw_ta + tw_r_in * twa, tw_a_out = role ? tw_r_col : tw_ta + tw_r_out * twa;
-    const int tw_b_in = role ? tw_cb + tw_r_col : tw_tb + tw_r_in * twb, tw_b_out = role ? tw_cb + tw_r_col : tw_tb + tw_r_out * twb;
-    uint32_t tva = 0, tvb = 0; // the column requested in the previous step ...
-    int tcol = -1;             // ... (image column; -1: none)
-    if constexpr (TW) {
-        for (int c = 0; c < 2 * half + kBandFill; ++c) {
-            t_store(t_lane_a, cwa, win.pa(c + g.pad_a), t_load(t_row_a, g.pitch_a, c + g.pad_a));
-            t_store(t_lane_b, cwb, win.pb(c + g.pad_b), t_load(t_row_b, g.pitch_b, c + g.pad_b));
-        }
-    }
-    const int slack = cwa - (2 * half + kBandRows + 2 + kBandFill); // columns the windows keep behind the last one any lane reads
     // window cost of candidate d at (x, y) from the cost at (x-1, y), from the cost at (x, y-1), or summed whole
     auto cost_slide = [&](uint32_t c_prev, int x, int d) -> uint32_t {
         if constexpr (MODE >= 0) {
@@ -1126,12 +1143,14 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
                 if (lo_a >= win.wa + win.cwa) win.wa += win.cwa;
                 if (lo_b >= win.wb + win.cwb) win.wb += win.cwb;
                 const int cn = k + 2 * half + kBandFill; // first read at step k + kBandFill
-                lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, lane);
-                lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, lane);
+                if constexpr (!TW) {
+                    lds_fill_column(g.A, g.pitch_a, g.h1, cn + g.pad_a, win.A + win.pa(cn + g.pad_a) * win.rp, win.row0, lds_rows, lane);
+                    lds_fill_column(g.B, g.pitch_b, g.h2, cn + g.pad_b, win.B + win.pb(cn + g.pad_b) * win.rp, win.row0, lds_rows, lane);
+                }
                 if constexpr (TW) {
                     if (tcol >= 0) {
-                        t_store(t_lane_a, cwa, win.pa(tcol + g.pad_a), tva);
-                        t_store(t_lane_b, cwb, win.pb(tcol + g.pad_b), tvb);
+                        t_store(t_lane_a, c_lane_a, cwa, win.pa(tcol + g.pad_a), tva);
+                        t_store(t_lane_b, c_lane_b, cwb, win.pb(tcol + g.pad_b), tvb);
                     }
                     tva = t_load(t_row_a, g.pitch_a, cn + g.pad_a);
                     tvb = t_load(t_row_b, g.pitch_b, cn + g.pad_b);
