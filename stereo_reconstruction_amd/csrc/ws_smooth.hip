@@ -936,7 +936,10 @@ constexpr unsigned long long kEdgeNone = ~0ull;
 constexpr int kBandSpinLimit = 1 << 20;
 
 constexpr int kBandDepth = 3; // steps a pixel's inputs (candidate list, map value, hand-off word) are requested ahead
-constexpr int kBandLag = 5;   // columns a band stays behind what its requests need from the band above
+#ifndef WS_BAND_LAG
+#define WS_BAND_LAG 3 // (development builds: tools/variants.py; 5 -> 3: -2.5 % at 7 x 7, profiles/r04/left_smooth.txt)
+#endif
+constexpr int kBandLag = WS_BAND_LAG; // columns a band stays behind what its requests need from the band above
 constexpr int kBandFill = 5;  // steps a window column is requested ahead of its first use
 
 // BS > 0 (with MODE >= 0): the block size at compile time.  The lines of the two common sliding sums -- the upper
