@@ -587,18 +587,46 @@ __device__ __forceinline__ bool left_better(double dist, int d, double bdist, in
 // cv::norm of the window, sqrt(cost) in double for SSD (BlockSearch.cpp:66) -- is taken here, by the data-parallel
 // pre-pass, so that the raster pass does not spend its one wave's issue slots on three double square roots a step.
 constexpr uint32_t kTopNone = 0xffffffffu; // above any window cost (63 * 63 * 3 * 255^2 < 2^30)
-constexpr int kTopWords = 12;              // dwords per pixel: 3 x {cost, d, distance lo, distance hi}
+constexpr int kTopWords = 12;              // dwords per pixel: 3 x {cost, d | table bits, distance lo, distance hi}
+// The d words: disparity in bits 0-19; bits 20-31 of the three together hold the pixel's 32-bit WINNER TABLE (12 + 12 + 8
+// bits): for each of the 4 x 4 cases "the upper neighbour's value is entry 0 / 1 / 2 / none of them" x "the left one's is
+// ...", which entry the reference's running minimum ends with (3: none) -- left_store_entry plays the 16 tournaments, with
+// the reference's doubles, on every CU; the one wave per band looks the answer up.
+constexpr int kTopTableShift = 20;
+constexpr uint32_t kTopDMask = (1u << kTopTableShift) - 1u;
+constexpr uint32_t kTopDNone = kTopDMask; // an empty entry's disparity field: no neighbour value equals it (d <= 65536)
 
 __device__ __forceinline__ void left_store_entry(const SmoothLeftArgs &g, uint32_t *t, uint32_t c0, int d0, uint32_t c1, int d1,
                                                  uint32_t c2, int d2)
 {
     const uint32_t c[3] = {c0, c1, c2};
     const int d[3] = {d0, d1, d2};
+    double m[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double m = c[i] == kTopNone ? 0.0 : left_dist_of(g, c[i]);
-        reinterpret_cast<uint4 *>(t)[i] = make_uint4(c[i], (uint32_t)d[i], (uint32_t)__double2loint(m), (uint32_t)__double2hiint(m));
+    for (int i = 0; i < 3; ++i) m[i] = c[i] == kTopNone ? 0.0 : left_dist_of(g, c[i]);
+    uint32_t table = 0;
+#pragma unroll
+    for (int iu = 0; iu < 4; ++iu) {
+#pragma unroll
+        for (int il = 0; il < 4; ++il) {
+            double dist = 1.7976931348623157e308; // (LeftBest, below: the running minimum of BlockSearch.cpp:50-79)
+            int bd = -1, w = 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (c[i] == kTopNone) continue;
+                double v = m[i];
+                if (iu == i) v *= g.s; // the upper factor first (:68-70)
+                if (il == i) v *= g.s; // the left factor second (:71-73)
+                if (v < dist || (v == dist && bd >= 0 && d[i] > bd)) { dist = v; bd = d[i]; w = i; }
+            }
+            table |= (uint32_t)w << (2 * (iu * 4 + il));
+        }
     }
+    const uint32_t bits[3] = {table & 0xfffu, (table >> 12) & 0xfffu, table >> 24};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        reinterpret_cast<uint4 *>(t)[i] = make_uint4(c[i], (c[i] == kTopNone ? kTopDNone : (uint32_t)d[i] & kTopDMask) | (bits[i] << kTopTableShift),
+                                                     (uint32_t)__double2loint(m[i]), (uint32_t)__double2hiint(m[i]));
 }
 
 __global__ void __launch_bounds__(256) ws_left_top3_kernel(const SmoothLeftArgs g, uint32_t *__restrict__ top, int top_pitch)
@@ -918,7 +946,7 @@ __device__ __forceinline__ void lds_fill_column(const uint32_t *plane, int pitch
 // Development build only (tools/band_stamps.py): s_memtime at five points of a step, steps [kStampStep0, +kStampSteps) of
 // every band; read back through ws_debug_band_stamps.  Each stamp waits for the scalar unit's counter (lgkmcnt(0)), so a
 // stamped step is a little longer than a plain one.
-constexpr int kStampBands = 32, kStampStep0 = 300, kStampSteps = 128, kStampPoints = 5;
+constexpr int kStampBands = 32, kStampStep0 = 300, kStampSteps = 128, kStampPoints = 8; // 0-4: the step's segments; 5-7: inside the decision
 __device__ unsigned long long ws_band_stamps[kStampBands][kStampSteps][kStampPoints];
 #define WS_STAMP(p)                                                                                        \
     do {                                                                                                   \
@@ -1314,19 +1342,30 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
                 const bool l_ok = x >= 1 && (float)l == lv && left_candidate_ok(g, x, l, half);
                 LeftBest b{1.7976931348623157e308, -1};
                 uint32_t bcost = 0; // integer window cost of the running winner
-                bool up_listed = false, l_listed = false;
-                const uint4 es[3] = {e0, e1, e2};
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (es[i].x == kTopNone) continue;
-                    const int d = (int)es[i].y;
-                    double m = __hiloint2double((int)es[i].w, (int)es[i].z); // the pre-pass took the root
-                    if (up_ok && up == d) { m *= g.s; up_listed = true; } // the upper factor first (:68-70)
-                    if (l_ok && l == d) { m *= g.s; l_listed = true; }    // the left factor second (:71-73)
-                    const int before = b.d;
-                    b.consider(m, d);
-                    if (b.d != before) bcost = es[i].x;
+                // the listed candidates: which of them the two neighbours' values are, then the pre-pass's table
+                const uint32_t table = (e0.y >> kTopTableShift) | ((e1.y >> kTopTableShift) << 12) | ((e2.y >> kTopTableShift) << 24);
+                const int ld0 = (int)(e0.y & kTopDMask), ld1 = (int)(e1.y & kTopDMask), ld2 = (int)(e2.y & kTopDMask);
+                // (index of the first entry a value equals, 3 if none, in plain arithmetic: ne_i = min(value ^ d_i, 1) is 0 on a
+                // match; a chain of compares, mask logic and selects runs through the scalar registers and costs a lone wave
+                // several times as much.  Empty entries hold kTopDNone, a value that may not take part kTopDNone - 1.)
+                auto first_match = [&](bool ok, int val) -> int {
+                    const uint32_t u = ok ? (uint32_t)val : kTopDNone - 1u;
+                    const uint32_t n0 = min(u ^ (uint32_t)ld0, 1u), n1 = min(u ^ (uint32_t)ld1, 1u), n2 = min(u ^ (uint32_t)ld2, 1u);
+                    return (int)(n0 * (1u + n1 * (1u + n2)));
+                };
+                const int iu = first_match(up_ok, up), il = first_match(l_ok, l);
+                const int w = (int)((table >> (2 * (iu * 4 + il))) & 3u);
+                bool up_listed = iu != 3, l_listed = il != 3;
+                b.d = w == 0 ? ld0 : w == 1 ? ld1 : w == 2 ? ld2 : -1;
+                bcost = w == 0 ? e0.x : w == 1 ? e1.x : e2.x;
+                // (its distance only where an unlisted neighbour value has to be compared with it)
+                if (other_can_win && ((up_ok && !up_listed) || (l_ok && !l_listed)) && w != 3) {
+                    double m = w == 0 ? __hiloint2double((int)e0.w, (int)e0.z) : w == 1 ? __hiloint2double((int)e1.w, (int)e1.z) : __hiloint2double((int)e2.w, (int)e2.z);
+                    if (iu == w) m *= g.s; // the upper factor first (:68-70)
+                    if (il == w) m *= g.s; // the left factor second (:71-73)
+                    b.dist = m;
                 }
+                WS_STAMP(5);
                 // the listed candidates' costs also serve the sliding sums below
                 uint32_t cu = 0;
                 bool cu_known = false;
@@ -1344,20 +1383,18 @@ __global__ void __launch_bounds__(kBandLanes) ws_smooth_left_bands_kernel(const 
                 } else if (up_ok && !up_listed && l_ok && l == up) {
                     l_listed = true; // (s >= 1: neither can win)
                 }
+                WS_STAMP(6);
                 if (l_ok && !l_listed && other_can_win) {
                     const uint32_t cl = slide_ok && lknown ? (PRE ? pre_slide(lcost) : cost_slide(lcost, x, l)) : cost_full(x, l);
                     const int before = b.d;
                     b.consider(left_dist_of(g, cl) * g.s, l);
                     if (b.d != before) bcost = cl;
                 }
+                WS_STAMP(7);
                 // remember the upper value's cost for the next column
                 if (up_ok) {
                     if (cu_known) { uv = up; ucost = cu; ux = x; }
-                    else if (up_listed) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            if (es[i].x != kTopNone && (int)es[i].y == up) { uv = up; ucost = es[i].x; ux = x; }
-                    }
+                    else if (iu != 3) { uv = up; ucost = iu == 0 ? e0.x : iu == 1 ? e1.x : e2.x; ux = x; } // (listed: its cost is in the list)
                 }
                 if (b.d >= 0) {
                     v = (float)b.d;

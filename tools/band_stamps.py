@@ -22,7 +22,7 @@ for bs in (7, 17):
     ctx.search_device(p, tl, tr, out, st)
     ms = ctx.timer_end(st)
     nb, ns, npnt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    buf = np.zeros(32 * 128 * 5, dtype=np.uint64)
+    buf = np.zeros(32 * 128 * 8, dtype=np.uint64)
     rc = lib.ws_debug_band_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nb), ctypes.byref(ns), ctypes.byref(npnt))
     s = buf.reshape(nb.value, ns.value, npnt.value).astype(np.int64)
     print("== %dx%d: call %.3f ms (instrumented), rc %d" % (bs, bs, ms, rc))
@@ -41,3 +41,8 @@ for bs in (7, 17):
     for i, name in enumerate(("fills+loads", "up/hand-off", "sliding sums", "decision")):
         d = t[:, :, i + 1] - t[:, :, i]
         print("   %-14s mean %.1f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % (name, d.mean(), *np.percentile(d, [10, 50, 90, 100])))
+    if npnt.value >= 8:  # inside the decision (stamps 5-7 are only written by steps whose lane 0 pixel has a list: zeros otherwise)
+        ok = (t[:, :, 5] > t[:, :, 3]) & (t[:, :, 7] > t[:, :, 5]) & (t[:, :, 4] > t[:, :, 7])
+        for name, a, b in (("list", 3, 5), ("upper value", 5, 6), ("left value", 6, 7), ("rest", 7, 4)):
+            d = (t[:, :, b] - t[:, :, a])[ok]
+            print("      %-12s mean %.1f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f   (%d steps)" % (name, d.mean(), *np.percentile(d, [10, 50, 90, 100]), d.size))
