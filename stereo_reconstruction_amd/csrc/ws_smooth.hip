@@ -246,9 +246,9 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
     GenericArgs e{}; // only the skip rectangle is used by ring_pixel
     e.skip_x0 = g.skip_x0; e.skip_x1 = g.skip_x1; e.skip_y0 = g.skip_y0; e.skip_y1 = g.skip_y1;
     const int lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pix = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (launch_smooth: the ring's pixel count is an int)
     int x, y; // original coordinates
-    if (!ring_pixel(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
+    if (!ring_pixel32(e, g.wa, g.ha, pix, &x, &y)) return; // uniform per wave
     const int xm = g.wa - 1 - x;
     float *o = g.out + (size_t)y * g.out_pitch + x;
     uint8_t code = kSelFixed;
@@ -288,12 +288,14 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const Prepa
                     ab = pix_sad(a[i], b[i], ab);
                 }
             }
+            // (a window is at most 16 x 16 pixels: every total -- at most 256 * 3 * 255^2 -- fits 32 bits with room to spare)
             long long c0, sa = 0;
             if constexpr (SSD) {
-                c0 = (long long)wave_sum_u64((unsigned long long)((long long)(int32_t)aa + (int32_t)bb - 2LL * (int32_t)ab));
-                sa = (long long)wave_sum_u64((unsigned long long)(long long)(int32_t)aa);
+                const long long taa = (long long)(int32_t)wave_sum_u32(aa), tbb = (long long)(int32_t)wave_sum_u32(bb);
+                c0 = taa + tbb - 2LL * (long long)(int32_t)wave_sum_u32(ab);
+                sa = taa;
             } else {
-                c0 = (long long)wave_sum_u64((unsigned long long)ab);
+                c0 = (long long)wave_sum_u32(ab);
             }
             val = *o; // (without a d >= 1 candidate: the search's fallback -x)
             const long long c1 = has_d1 ? (long long)g.cost[(size_t)y * g.cost_pitch + x] + sa : 0LL;
