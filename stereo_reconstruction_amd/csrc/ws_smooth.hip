@@ -237,6 +237,45 @@ __global__ void __launch_bounds__(256) ws_smooth_prepare_box_kernel(const Prepar
     }
 }
 
+// The same for 32-bit terms (modulo 2^32: exact, signed or not, whenever the total fits), all 64 lanes active: six DPP
+// additions -- Hillis-Steele inside the rows of 16 lanes, the row totals across the rows -- instead of six trips through
+// the LDS crossbar; the total is lane 63's.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // lane 15 of rows 0, 2 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // lane 31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// (ring_pixel's enumeration in 32-bit arithmetic, for callers whose pixel count fits: a 64-bit division is ~100 instructions)
+__device__ __forceinline__ bool ring_pixel32(const GenericArgs &g, int ow, int oh, uint32_t idx, int *px, int *py)
+{
+    const uint32_t w = (uint32_t)ow;
+    const uint32_t n_top = (uint32_t)g.skip_y0 * w, n_bot = (uint32_t)(oh - g.skip_y1) * w;
+    const uint32_t side = (uint32_t)(g.skip_x0 + (ow - g.skip_x1));
+    const uint32_t n_side = (uint32_t)(g.skip_y1 - g.skip_y0) * side;
+    if (idx < n_top) {
+        *py = (int)(idx / w);
+        *px = (int)(idx % w);
+    } else if (idx < n_top + n_bot) {
+        idx -= n_top;
+        *py = g.skip_y1 + (int)(idx / w);
+        *px = (int)(idx % w);
+    } else if (idx < n_top + n_bot + n_side) {
+        idx -= n_top + n_bot;
+        *py = g.skip_y0 + (int)(idx / side);
+        const int k = (int)(idx % side);
+        *px = k < g.skip_x0 ? k : g.skip_x1 + (k - g.skip_x0);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 template <bool SSD, bool CENTRED>
 __global__ void __launch_bounds__(256) ws_smooth_prepare_ring_kernel(const PreparePlanesArgs g)
 {
