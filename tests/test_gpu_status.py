@@ -55,3 +55,33 @@ def test_no_flag_without_the_knob(wslib, gpu_ctx, oracle):
     got = wslib.BlockSearch(left, right, 7, 0, 32, context=gpu_ctx).computeDisparityMapLeft(0.9)
     gpu_ctx.device_status()
     assert np.array_equal(got, oracle.block_left(left, right, 7, 0, 32, smooth=0.9))
+
+
+# The raster pass has two forms of its compile-time-window kernel: with a second, row-major copy of the LDS windows (the
+# default wherever both copies fit) and without (wide disparity ranges; smoothFactor >= 1).  WS_LEFT_TW=0 (development
+# knob, read once per process) takes the second for every call, so that both are held against the oracle on the same
+# inputs -- sliding sums included (smoothFactor < 1) -- whatever shapes the other tests happen to use.
+CHILD_FORMS = r"""
+import sys
+import numpy as np
+import stereo_reconstruction_amd as ws
+from stereo_reconstruction_amd.synthetic import make_pair
+from oracle import oracle
+ctx = ws.WindowSearch(0)
+for (w, h, bs, D, s, cost, seed) in ((260, 150, 7, 48, 0.9, "ssd", 3), (230, 140, 17, 40, 0.5, "ssd", 4), (250, 130, 9, 64, 0.9, "sad", 5),
+                                      (240, 120, 5, 32, -0.5, "ssd", 6)):
+    left, right, _ = make_pair(w, h, D, seed=seed)
+    got = ws.BlockSearch(left, right, bs, 0, D, context=ctx, cost=cost).computeDisparityMapLeft(s)
+    want = oracle.block_left(left, right, bs, 0, D, smooth=s, cost=cost)
+    print("FORM", bs, s, cost, bool(np.array_equal(got, want)))
+print("DONE")
+"""
+
+
+@pytest.mark.parametrize("knob", ["0", "1"])
+def test_both_forms_of_the_raster_pass_equal_the_oracle(knob):
+    env = dict(os.environ, WS_LEFT_TW=knob, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", CHILD_FORMS], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("FORM")]
+    assert len(lines) == 4 and all(l.endswith("True") for l in lines) and "DONE" in r.stdout, r.stdout + r.stderr
