@@ -435,7 +435,7 @@ def test_reconstruction_consumers(wslib, gpu_ctx, oracle, tmp_path):
 def test_randomised_differential(wslib, gpu_ctx, oracle, seed):
     """Random shapes / windows / ranges / views against the oracle: tile edges, D not a multiple
     of the chunk, D larger than the image, unequal sizes, black patches, few grey levels."""
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + int(os.environ.get("WS_FUZZ_BASE", "0")) + seed)   # (WS_FUZZ_BASE: fresh cases)
     w1, h1 = int(rng.integers(20, 420)), int(rng.integers(12, 90))
     same = rng.random() < 0.5
     w2 = w1 if same else max(8, w1 + int(rng.integers(-40, 41)))
