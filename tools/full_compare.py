@@ -17,7 +17,7 @@ ctx = ws.WindowSearch(0)
 for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
     w, h, bs, cost, maxd, seed = WORKLOADS[name]
     left, right, _ = make_pair(w, h, maxd, seed)
-    for view in ("left", "right"):
+    for view in (("left",) if "--left-only" in sys.argv else ("left", "right")):
         b = ws.BlockSearch(left, right, bs, 0, maxd, cost=cost, context=ctx)
         t0 = time.time()
         got = b.computeDisparityMapLeft(1.0) if view == "left" else b.computeDisparityMapRight(1.0)
